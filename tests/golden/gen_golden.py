@@ -1,0 +1,423 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference, read-only).  It never runs on
+the GPU box and nothing here is imported by the product path.  What is committed are the
+*outputs* (.npz data: inputs + expected outputs) and this script — no reference source.
+
+How the reference is driven:
+  * `bridgestan` is absent; an EMPTY module object of that name is put in sys.modules so
+    that `klhr_sinh` / `bsmodel` import.  `BSModel` is never constructed.
+  * The log density is supplied by NumPy stand-ins with the BSModel surface
+    (oracle/standin_models.py) — closed forms derived from the reference's Stan programs.
+    Parity at the BridgeStan boundary itself is therefore UNPINNED.
+  * Everything else (KLHRSINH, MH, OnlineMoments, OnlinePCA, WindowedAdaptation, NumPy
+    PCG64/ziggurat/multivariate_normal, SciPy BFGS) is the reference's own unmodified code
+    running on this container's NumPy 2.2.6 / SciPy 1.15.3.
+
+Usage:  python tests/golden/gen_golden.py            (≈ 2–4 min, writes tests/golden/*.npz)
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+
+sys.modules.setdefault("bridgestan", types.ModuleType("bridgestan"))
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+
+import klhr_sinh as ref_klhr_sinh          # noqa: E402  (reference)
+import mh as ref_mh                        # noqa: E402
+import onlinemoments as ref_om             # noqa: E402
+import onlinepca as ref_pca                # noqa: E402
+import windowedadaptation as ref_wa        # noqa: E402
+from oracle import standin_models as sm    # noqa: E402
+
+MASK64 = (1 << 64) - 1
+
+
+def st4(rng):
+    """PCG64 (state, inc) as 4 u64: [state_hi, state_lo, inc_hi, inc_lo]."""
+    s = rng.bit_generator.state["state"]
+    return np.array([s["state"] >> 64, s["state"] & MASK64, s["inc"] >> 64, s["inc"] & MASK64],
+                    dtype=np.uint64)
+
+
+def clone_rng(rng):
+    r = np.random.default_rng(0)
+    r.bit_generator.state = rng.bit_generator.state
+    return r
+
+
+def glmm_data():
+    with open(os.path.join(ROOT, "klhr_amd", "stan", "glmm-poisson.json")) as f:
+        return json.load(f)
+
+
+def make_model(name):
+    if name == "funnel10":
+        return sm.Funnel(9)
+    if name == "funnel100":
+        return sm.Funnel(99)
+    if name == "illnormal100":
+        return sm.IllNormal(100)
+    if name == "glmm45":
+        d = glmm_data()
+        return sm.GlmmPoisson(d["year"], d["C"])
+    if name == "normal2":
+        return sm.Normal(2)
+    if name == "normal100":
+        return sm.Normal(100)
+    raise KeyError(name)
+
+
+# --------------------------------------------------------------------------------------
+def g1_quadrature():
+    a = ref_klhr_sinh.KLHRSINH(make_model("normal2"), seed=0, overrelaxed=False)
+    np.savez(os.path.join(HERE, "g1_quadrature.npz"), x=a.x, w=a.w)
+
+
+def g2_rng():
+    out = {}
+    seeds = [0, 1, 2, 3, 12345]
+    out["seeds"] = np.array(seeds, dtype=np.uint64)
+    n = 4096
+    for s in seeds:
+        rng = np.random.default_rng(s)
+        out[f"s{s}_state0"] = st4(rng)
+        out[f"s{s}_raw"] = clone_rng(rng).bit_generator.random_raw(n)
+        out[f"s{s}_double"] = clone_rng(rng).random(n)
+        r = clone_rng(rng)
+        out[f"s{s}_normal"] = r.standard_normal(n)
+        out[f"s{s}_uniform_after"] = np.array([r.uniform()])
+        out[f"s{s}_state_after"] = st4(r)
+    # long normal stream: exercises wedge + tail paths many times
+    r = np.random.default_rng(2024)
+    out["long_state0"] = st4(r)
+    z = r.standard_normal(200_000)
+    out["long_sum"] = np.array([z.sum(), (z * z).sum(), np.abs(z).max()])
+    out["long_tail_idx"] = np.flatnonzero(np.abs(z) > 3.6541528853610088).astype(np.int64)
+    out["long_tail_val"] = z[np.abs(z) > 3.6541528853610088]
+    out["long_every"] = z[::997].copy()
+    out["long_state_after"] = st4(r)
+    # normal(scale=0.1,size=D) as used by MCMCBase (mcmc.py:15) and normal(size=D)*0.1 (klhr_sinh.py:90)
+    r = np.random.default_rng(5)
+    out["scale_state0"] = st4(r)
+    out["scale_a"] = r.normal(scale=0.1, size=10)
+    out["scale_b"] = r.normal(size=10) * 0.1
+    out["scale_c"] = np.array([r.normal() * 0.1])
+    # multivariate_normal(m, diag(c)) cases (klhr_sinh.py:211-212)
+    g = np.random.default_rng(99)
+    cases = []
+    for D, kind in [(10, "rand"), (10, "rand"), (25, "rand"), (45, "rand"), (100, "ones"), (100, "rand"),
+                    (10, "zeros"), (10, "ones")]:
+        if kind == "rand":
+            c = g.uniform(0.05, 3.0, size=D)
+        elif kind == "ones":
+            c = np.ones(D)
+        else:
+            c = np.zeros(D)
+        m = g.normal(size=D)
+        r = np.random.default_rng(1000 + len(cases))
+        s0 = st4(r)
+        x = r.multivariate_normal(m, np.diag(c))
+        cases.append((D, s0, m, c, x, st4(r)))
+    out["mvn_n"] = np.array([len(cases)])
+    for i, (D, s0, m, c, x, s1) in enumerate(cases):
+        out[f"mvn{i}_state0"] = s0
+        out[f"mvn{i}_m"] = m
+        out[f"mvn{i}_c"] = c
+        out[f"mvn{i}_x"] = x
+        out[f"mvn{i}_state1"] = s1
+    # rng.choice(n, p=p) as used by eigen_method_one (klhr_sinh.py:207)
+    r = np.random.default_rng(77)
+    out["choice_state0"] = st4(r)
+    p = np.array([0.2, 0.5, 0.3])
+    out["choice_p"] = p
+    out["choice_j"] = np.array([r.choice(3, p=p) for _ in range(256)], dtype=np.int64)
+    out["choice_state1"] = st4(r)
+    np.savez(os.path.join(HERE, "g2_rng.npz"), **out)
+
+
+def g3_primitives():
+    a = ref_klhr_sinh.KLHRSINH(make_model("normal2"), seed=0, overrelaxed=False)
+    g = np.random.default_rng(31)
+    etas = g.normal(size=(64, 4))
+    etas[:8] *= 0.1
+    etas[8:16, 1:3] *= 3.0
+    etas[16] = [0.3, 301.5, 0.2, -0.4]      # |eta1| > 300 clip
+    etas[17] = [0.3, -305.0, 0.2, 0.4]
+    etas[18] = [-0.2, 0.1, 302.0, 0.4]      # |eta2| > 300 clip
+    etas[19] = [-0.2, 0.1, -310.0, 0.4]
+    etas[20] = [0.0, 0.0, -6.0, 5.0]        # sinh/cosh/tanh argument clip at +-300
+    etas[21] = [1.0, 2.0, -7.0, -3.0]
+    xs = np.concatenate([a.x, [0.0, 10.0, -10.0, 0.5, -1e-3]])
+    ys = np.array([0.0, 0.7, -2.5, 10.0, -10.0, 1e-4])
+    T = np.zeros((64, xs.size))
+    laj = np.zeros((64, xs.size))
+    gT = np.zeros((64, xs.size, 4))
+    glaj = np.zeros((64, xs.size, 4))
+    Tinv = np.zeros((64, ys.size))
+    logq = np.zeros((64, ys.size))
+    with np.errstate(all="ignore"):
+        for i, eta in enumerate(etas):
+            for j, x in enumerate(xs):
+                T[i, j] = a._T(x, eta)
+                laj[i, j] = a._log_abs_jac(x, eta)
+                gT[i, j] = a._grad_T(x, eta)
+                glaj[i, j] = a._grad_log_abs_jac(x, eta)
+            for j, y in enumerate(ys):
+                Tinv[i, j] = a._T_inv(y, eta)
+                logq[i, j] = a._log_q(y, eta)
+    np.savez(os.path.join(HERE, "g3_primitives.npz"), etas=etas, xs=xs, ys=ys, T=T, log_abs_jac=laj,
+             grad_T=gT, grad_log_abs_jac=glaj, T_inv=Tinv, log_q=logq)
+
+
+def g4_kl():
+    out = {}
+    for name in ["funnel10", "illnormal100", "glmm45", "normal2", "funnel100"]:
+        model = make_model(name)
+        a = ref_klhr_sinh.KLHRSINH(model, seed=11, overrelaxed=False)
+        D = a.D
+        g = np.random.default_rng(41)
+        n = 64
+        thetas = g.normal(size=(n, D)) * np.where(np.arange(n) % 4 == 3, 1.5, 0.3)[:, None]
+        rhos = g.normal(size=(n, D))
+        rhos /= np.linalg.norm(rhos, axis=1)[:, None]
+        etas = g.normal(size=(n, 4)) * 0.3
+        etas[n // 2:, 1] += 1.0            # wide proposals: exercises the +-300 gradient clip
+        if name.startswith("funnel"):
+            thetas[5, 0] = -9.0            # narrow neck: huge gradients -> clip
+            thetas[6, 0] = 7.0
+        vals = np.zeros(n)
+        grads = np.zeros((n, 4))
+        lps = np.zeros(n)
+        lgs = np.zeros((n, D))
+        line = np.zeros((n, 2))
+        with np.errstate(all="ignore"):
+            for i in range(n):
+                a.theta = thetas[i]
+                vals[i], grads[i] = a.KL(etas[i], rhos[i])
+                lps[i], lgs[i] = model.log_density_gradient(thetas[i])
+                line[i] = a.logp_grad_rho(etas[i, 0], rhos[i])
+        out.update({f"{name}_theta": thetas, f"{name}_rho": rhos, f"{name}_eta": etas,
+                    f"{name}_kl": vals, f"{name}_klgrad": grads, f"{name}_lp": lps, f"{name}_lpgrad": lgs,
+                    f"{name}_line": line})
+    np.savez(os.path.join(HERE, "g4_kl.npz"), **out)
+
+
+def g7_online():
+    out = {}
+    g = np.random.default_rng(71)
+    for D in (3, 10):
+        X = g.normal(size=(70, D)) * np.linspace(0.5, 2.0, D)
+        om = ref_om.OnlineMoments(D)
+        pca = ref_pca.OnlinePCA(D, K=2, l=4)
+        ms, vs, vars_, pv, pvals, pvecs = [], [], [], [], [], []
+        for x in X:
+            om.update(x)
+            pca.update(x.copy())
+            ms.append(om.m.copy())
+            vs.append(om.v.copy())
+            vars_.append(np.array(om.var(), dtype=np.float64).copy())
+            pv.append(pca.v.copy())
+            pvals.append(pca.values().copy())
+            pvecs.append(pca.vectors().copy())
+        out.update({f"D{D}_X": X, f"D{D}_m": np.array(ms), f"D{D}_v": np.array(vs), f"D{D}_var": np.array(vars_),
+                    f"D{D}_pcav": np.array(pv), f"D{D}_pcavals": np.array(pvals),
+                    f"D{D}_pcavecs": np.array(pvecs)})
+    settings = [(100, 50, 2), (1000, 50, 2), (100, 25, 2), (0, 50, 2), (30, 50, 2), (20000, 50, 2), (5000000, 50, 2),
+                (1000, 25, 3)]
+    out["wa_settings"] = np.array(settings, dtype=np.int64)
+    for i, (wu, ws, sc) in enumerate(settings):
+        wa = ref_wa.WindowedAdaptation(wu, windowsize=ws, windowscale=sc)
+        out[f"wa{i}_closures"] = np.array(wa._closures, dtype=np.int64)
+        if wu <= 1000:
+            wa2 = ref_wa.WindowedAdaptation(wu, windowsize=ws, windowscale=sc)
+            closed = [m for m in range(1, 1200) if wa2.window_closed(m)]
+            out[f"wa{i}_closed"] = np.array(closed, dtype=np.int64)
+    np.savez(os.path.join(HERE, "g7_online.npz"), **out)
+
+
+# --------------------------------------------------------------------------------------
+SNAP_DRAWS = {1, 2, 3, 5, 6, 7, 10, 25, 49, 50, 51, 52, 60, 99, 100, 101, 120, 150}
+
+
+def trace_chain(name, seed, M, warmup, **flags):
+    """Run the reference KLHRSINH for M draws, recording per-iteration inputs/outputs."""
+    model = make_model(name)
+    algo = ref_klhr_sinh.KLHRSINH(model, seed=seed, warmup=warmup, overrelaxed=False, **flags)
+    D = algo.D
+    rec = {k: [] for k in
+           ["state_before", "theta_before", "rho", "x0", "mode", "hinv1", "nfev1", "nit1", "status1", "init", "eta",
+            "nfev2", "nit2", "status2", "fun2", "state_mh", "zp", "r", "logu", "accept", "theta_after", "accprob",
+            "grad_evals", "state_after"]}
+    snaps = {}
+    theta0 = algo.theta.copy()
+    state_init = st4(algo.rng)
+    results = []
+    real_minimize = ref_klhr_sinh.minimize
+
+    def rec_minimize(fun, x0, *a, **k):
+        x0c = np.array(x0, dtype=np.float64).reshape(-1).copy()
+        o = real_minimize(fun, x0, *a, **k)
+        results.append((o, x0c))
+        return o
+
+    ref_klhr_sinh.minimize = rec_minimize
+    try:
+        for m in range(1, M + 1):
+            rec["state_before"].append(st4(algo.rng))
+            th0 = algo.theta.copy()
+            rec["theta_before"].append(th0)
+            # --- replicate draw() body step by step with the reference's own methods (klhr_sinh.py:262-289)
+            algo._draw += 1
+            rho = algo._random_direction()
+            results.clear()
+            eta = algo.fit(rho)
+            (o1, x01), (o2, x02) = results
+            rec["x0"].append(float(x01[0]))
+            rec["init"].append(x02)
+            rec["rho"].append(rho.copy())
+            rec["mode"].append(float(o1.x[0]))
+            rec["hinv1"].append(float(o1.hess_inv[0, 0]))
+            rec["nfev1"].append(o1.nfev)
+            rec["nit1"].append(o1.nit)
+            rec["status1"].append(o1.status)
+            rec["eta"].append(eta.copy())
+            rec["nfev2"].append(o2.nfev)
+            rec["nit2"].append(o2.nit)
+            rec["status2"].append(o2.status)
+            rec["fun2"].append(float(o2.fun))
+            rec["state_mh"].append(st4(algo.rng))
+            # MH step internals replayed on a cloned generator (klhr_sinh.py:242-260)
+            rc = clone_rng(algo.rng)
+            z = rc.normal(size=1)
+            with np.errstate(all="ignore"):
+                zp = algo._T(z, eta)
+                thetap = zp * rho + th0
+                r = model.log_density(thetap)
+                r -= model.log_density(th0)
+                r += algo._log_q(0, eta)
+                r -= algo._log_q(zp, eta)
+                logu = np.log(rc.uniform())
+                theta = algo._metropolis_step(eta, rho)
+            a = bool(logu < np.minimum(0, r))
+            rec["zp"].append(float(zp[0]))
+            rec["r"].append(float(np.asarray(r).reshape(-1)[0]))
+            rec["logu"].append(float(logu))
+            rec["accept"].append(a)
+            assert np.array_equal(st4(rc), st4(algo.rng))
+            # closure-or-update branch, verbatim order of klhr_sinh.py:268-287
+            if algo._windowedadaptation.window_closed(algo._draw):
+                algo._mean = algo._onlinemoments.mean()
+                algo._cov = algo._onlinemoments.var()
+                if algo._scale_dir_cov:
+                    algo._cov /= (algo._tol + algo._onlinemoments_density.var())
+                algo._onlinemoments_density.reset()
+                algo._onlinemoments.reset()
+                algo._eigvecs[:, :algo.J] = algo._onlinepca.vectors()
+                algo._eigvals[:algo.J] = algo._onlinepca.values()
+                algo._onlinepca.reset()
+                algo._smoothK.optimum()
+                algo._smoothK.reset()
+            else:
+                _, g = algo._logp_grad(theta)
+                algo._onlinemoments_density.update(g)
+                algo._onlinemoments.update(theta)
+                algo._onlinepca.update(theta - algo._mean)
+                msjd = np.linalg.norm(theta - algo._prev_theta)
+                algo._smoothK.update(2 * (msjd > algo._msjd) - 1)
+            rec["theta_after"].append(np.array(theta, dtype=np.float64).copy())
+            rec["accprob"].append(float(np.asarray(algo.acceptance_probability).reshape(-1)[0]))
+            rec["grad_evals"].append(int(algo.grad_evals))
+            rec["state_after"].append(st4(algo.rng))
+            if m in SNAP_DRAWS:
+                snaps[m] = dict(mean=np.array(algo._mean, dtype=np.float64).copy(),
+                                cov=np.array(algo._cov, dtype=np.float64).copy(),
+                                eigvecs=algo._eigvecs.copy(), eigvals=algo._eigvals.copy(),
+                                om_N=algo._onlinemoments.N, om_m=algo._onlinemoments.m.copy(),
+                                om_v=algo._onlinemoments.v.copy(),
+                                omd_N=algo._onlinemoments_density.N, omd_m=algo._onlinemoments_density.m.copy(),
+                                omd_v=algo._onlinemoments_density.v.copy(),
+                                pca_n=algo._onlinepca.n, pca_v=algo._onlinepca.v.copy())
+    finally:
+        ref_klhr_sinh.minimize = real_minimize
+    out = {"theta0": theta0, "state_init": state_init, "seed": np.array([seed]), "M": np.array([M]),
+           "warmup": np.array([warmup]), "D": np.array([D]),
+           "flags": np.array([int(flags.get("scale_dir_cov", False)), int(flags.get("eigen_method_one", False))])}
+    for k, v in rec.items():
+        out[k] = np.array(v)
+    out["snap_draws"] = np.array(sorted(snaps), dtype=np.int64)
+    for m, s in snaps.items():
+        for k, v in s.items():
+            out[f"snap{m}_{k}"] = np.asarray(v)
+    return out
+
+
+def g8_chains():
+    jobs = []
+    for seed in range(4):
+        jobs.append(("funnel10", seed, 1000, 100, {}))
+    for seed in range(2):
+        jobs.append(("illnormal100", seed, 160, 100, {}))
+        jobs.append(("glmm45", seed, 160, 100, {}))
+    jobs.append(("funnel100", 0, 120, 100, {}))
+    jobs.append(("normal2", 0, 300, 100, {}))
+    jobs.append(("funnel10", 5, 200, 100, {"eigen_method_one": True}))
+    jobs.append(("funnel10", 6, 200, 100, {"scale_dir_cov": True}))
+    jobs.append(("funnel10", 7, 400, 1000, {}))     # constructor-default warmup: closures 50,150,350,1000
+    for name, seed, M, warmup, flags in jobs:
+        tag = "".join(k[0] for k in sorted(flags))  # "", "e", "s"
+        fn = os.path.join(HERE, f"g8_{name}_s{seed}_w{warmup}{('_' + tag) if tag else ''}.npz")
+        print("tracing", fn, flush=True)
+        out = trace_chain(name, seed, M, warmup, **flags)
+        np.savez(fn, **out)
+
+
+def g8_untouched():
+    """Free-running reference chains driven ONLY through the public draw() — guards the
+    step-by-step replication in trace_chain against the reference's real control flow."""
+    out = {}
+    for seed in (0, 1):
+        algo = ref_klhr_sinh.KLHRSINH(make_model("funnel10"), seed=seed, warmup=100, overrelaxed=False)
+        th = np.array([algo.draw() for _ in range(150)])
+        out[f"s{seed}_thetas"] = th
+        out[f"s{seed}_acc"] = np.asarray(algo.acceptance_probability, dtype=np.float64).reshape(-1)
+        out[f"s{seed}_grad_evals"] = np.array([algo.grad_evals])
+    algo = ref_klhr_sinh.KLHRSINH(make_model("normal2"), seed=3, warmup=100, overrelaxed=False)
+    out["sample_normal2"] = algo.sample(50)          # mcmc.py:31-37: row 0 is the initial point
+    np.savez(os.path.join(HERE, "g8_public_api.npz"), **out)
+
+
+def g9_mh():
+    out = {}
+    for name in ("normal2", "normal100"):
+        for seed in (0, 1):
+            model = make_model(name)
+            a = ref_mh.MH(model, 0.09, seed=seed)
+            th0 = a.theta.copy()
+            s0 = st4(a.rng)
+            th = np.array([a.draw().copy() for _ in range(2000)])
+            out[f"{name}_s{seed}_theta0"] = th0
+            out[f"{name}_s{seed}_state0"] = s0
+            out[f"{name}_s{seed}_thetas"] = th[::10].copy() if name == "normal100" else th
+            out[f"{name}_s{seed}_last"] = th[-1]
+            out[f"{name}_s{seed}_acc"] = np.array([float(a.acceptance_probability)])
+            out[f"{name}_s{seed}_state1"] = st4(a.rng)
+    np.savez(os.path.join(HERE, "g9_mh.npz"), **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g7", "g8", "g8p", "g9"]
+    fns = {"g1": g1_quadrature, "g2": g2_rng, "g3": g3_primitives, "g4": g4_kl, "g7": g7_online,
+           "g8": g8_chains, "g8p": g8_untouched, "g9": g9_mh}
+    for w in which:
+        print("==", w, flush=True)
+        fns[w]()
