@@ -1,0 +1,50 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+STAN = os.path.join(ROOT, "klhr_amd", "stan")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def model_spec(name):
+    """fixture name -> (stan stem, data dict)"""
+    if name == "funnel10":
+        return "funnel", {"D": 9}
+    if name == "funnel100":
+        return "funnel", {"D": 99}
+    if name == "illnormal100":
+        return "ill-normal", {"D": 100}
+    if name == "normal2":
+        return "normal", {"D": 2}
+    if name == "normal100":
+        return "normal", {"D": 100}
+    if name == "glmm45":
+        with open(os.path.join(STAN, "glmm-poisson.json")) as f:
+            return "glmm-poisson", json.load(f)
+    raise KeyError(name)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as O
+    O.build()
+    return O
+
+
+def has_gpu():
+    return os.path.exists("/dev/kfd")
