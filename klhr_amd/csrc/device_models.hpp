@@ -1,0 +1,120 @@
+// device_models.hpp — the log densities behind BSModel (bsmodel.py:15-30) as gfx950 device functions.
+//
+// BridgeStan defaults propto=True, jacobian=True (bsmodel.py:18,27 pass no kwargs): constants dropped,
+// change-of-variables terms included.  Closed forms are derived from the reference's Stan programs:
+//   FUNNEL        stan/funnel.stan:4-10       theta = (v, alpha_1..alpha_Da)
+//                 lp = -v^2/18 - Da*v/2 - exp(-v)*sum(alpha^2)/2
+//   ILL_NORMAL    stan/ill-normal.stan:4-11   s_i = i/sqrt(D);  lp = -sum((y_i/s_i)^2)/2
+//   GLMM_POISSON  stan/glmm-poisson.stan:6-29 theta = (alpha, beta_1..3, log sigma, eps~_1..n)
+//                 lp = -alpha^2/50 - sum(beta^2)/50 - l^2/2 - sum(eps~^2)/2 + sum(C_i*eta_i - exp(eta_i)),
+//                 eta_i = alpha + x_i.beta + exp(l)*eps~_i
+//   NORMAL        stan/normal.stan:4-8        lp = -sum(y^2)/2
+//
+// One generic evaluator per model:  model_eval<MODEL>(md, xr, cl, sink, logp, gdot)
+//   xr(i, xi, ri)   supplies coordinate i of the evaluation point and of the direction rho
+//   cl              element-wise gradient clip bound (+inf = no clip): KLHRSINH._logp_grad clips at
+//                   +-scale_clip (klhr_sinh.py:158-161), logp_grad_rho does not (klhr_sinh.py:178-180)
+//   sink(i, g_i)    receives the UNclipped gradient component (no-op functor for line evaluations)
+//   gdot            = sum_i clip(g_i) * rho_i   — the only thing the hot loop needs from the gradient
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace klhr {
+
+enum { MODEL_FUNNEL = 0, MODEL_ILL_NORMAL = 1, MODEL_GLMM_POISSON = 2, MODEL_NORMAL = 3 };
+
+struct ModelData {
+    const double *aux;   // ILL_NORMAL: [1/s_i (D)] ; GLMM: [x1(n), x2(n), x3(n), C(n)]
+    int D;               // unconstrained dimension
+    int n;               // GLMM: years ; FUNNEL: Da
+};
+
+// np.clip semantics: NaN passes through
+__device__ __forceinline__ double clipc(double x, double c) { return x < -c ? -c : (x > c ? c : x); }
+
+struct NoSink {
+    __device__ __forceinline__ void operator()(int, double) const {}
+};
+
+template <int MODEL, class XR, class SINK>
+__device__ __forceinline__ void model_eval(const ModelData &md, XR xr, double cl, SINK sink, double &logp, double &gdot) {
+    const int D = md.D;
+    if constexpr (MODEL == MODEL_FUNNEL) {
+        double v, r0;
+        xr(0, v, r0);
+        const double Da = (double)md.n;
+        const double ev = exp(-v);
+        double ss = 0.0, gd = 0.0;
+        for (int i = 1; i < D; i++) {
+            double xi, ri;
+            xr(i, xi, ri);
+            ss += xi * xi;
+            double gi = -ev * xi;
+            sink(i, gi);
+            gd += clipc(gi, cl) * ri;
+        }
+        double g0 = -v / 9.0 - 0.5 * Da + 0.5 * ev * ss;
+        sink(0, g0);
+        gdot = clipc(g0, cl) * r0 + gd;
+        logp = -v * v / 18.0 - 0.5 * Da * v - 0.5 * ev * ss;
+    } else if constexpr (MODEL == MODEL_ILL_NORMAL) {
+        double acc = 0.0, gd = 0.0;
+        for (int i = 0; i < D; i++) {
+            double xi, ri;
+            xr(i, xi, ri);
+            double is = md.aux[i];
+            double z = xi * is;
+            acc += z * z;
+            double gi = -z * is;
+            sink(i, gi);
+            gd += clipc(gi, cl) * ri;
+        }
+        gdot = gd;
+        logp = -0.5 * acc;
+    } else if constexpr (MODEL == MODEL_NORMAL) {
+        double acc = 0.0, gd = 0.0;
+        for (int i = 0; i < D; i++) {
+            double xi, ri;
+            xr(i, xi, ri);
+            acc += xi * xi;
+            sink(i, -xi);
+            gd += clipc(-xi, cl) * ri;
+        }
+        gdot = gd;
+        logp = -0.5 * acc;
+    } else {   // MODEL_GLMM_POISSON
+        const int n = md.n;
+        const double *x1 = md.aux, *x2 = md.aux + n, *x3 = md.aux + 2 * n, *Cn = md.aux + 3 * n;
+        double alpha, b0, b1, b2, ell, ra, rb0, rb1, rb2, rl;
+        xr(0, alpha, ra); xr(1, b0, rb0); xr(2, b1, rb1); xr(3, b2, rb2); xr(4, ell, rl);
+        const double sigma = exp(ell);
+        double lp = -alpha * alpha / 50.0;
+        lp -= b0 * b0 / 50.0; lp -= b1 * b1 / 50.0; lp -= b2 * b2 / 50.0;
+        lp -= 0.5 * ell * ell;
+        double sr = 0, s1 = 0, s2 = 0, s3 = 0, sre = 0, see = 0, lik = 0, gd = 0;
+        for (int i = 0; i < n; i++) {
+            double e, re;
+            xr(5 + i, e, re);
+            double eta = alpha + x1[i] * b0 + x2[i] * b1 + x3[i] * b2 + sigma * e;
+            double mu = exp(eta);
+            double r = Cn[i] - mu;
+            lik += Cn[i] * eta - mu;
+            see += e * e;
+            sr += r; s1 += x1[i] * r; s2 += x2[i] * r; s3 += x3[i] * r;
+            sre += r * e;
+            double ge = -e + sigma * r;
+            sink(5 + i, ge);
+            gd += clipc(ge, cl) * re;
+        }
+        lp += -0.5 * see + lik;
+        double g0 = -alpha / 25.0 + sr, g1 = -b0 / 25.0 + s1, g2 = -b1 / 25.0 + s2, g3 = -b2 / 25.0 + s3;
+        double g4 = -ell + sigma * sre;
+        sink(0, g0); sink(1, g1); sink(2, g2); sink(3, g3); sink(4, g4);
+        gd += clipc(g0, cl) * ra; gd += clipc(g1, cl) * rb0; gd += clipc(g2, cl) * rb1; gd += clipc(g3, cl) * rb2;
+        gd += clipc(g4, cl) * rl;
+        gdot = gd;
+        logp = lp;
+    }
+}
+
+}  // namespace klhr

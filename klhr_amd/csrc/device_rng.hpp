@@ -1,0 +1,67 @@
+// device_rng.hpp — NumPy-compatible PCG64 + 256-layer ziggurat normal on gfx950.
+//
+// The reference draws every random number from np.random.default_rng(seed) (mcmc.py:9-15;
+// klhr_sinh.py:90,184,191,212,246,254).  To match it chain-for-chain the device generator must be
+// NumPy's: PCG64 (128-bit LCG, XSL-RR output) and the ziggurat standard normal of
+// numpy/random/src/distributions/distributions.c.  rocRAND cannot reproduce this stream.
+// One generator per chain; all 8 lanes of a chain's octet hold an identical copy in registers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define KLHR_ZIG_QUAL static __device__ const
+#include "zig_tables.h"
+
+namespace klhr {
+
+typedef unsigned __int128 u128;
+
+struct Pcg64 {
+    uint64_t sh, sl, ih, il;   // state hi/lo, increment hi/lo
+};
+
+__device__ __forceinline__ uint64_t pcg_next64(Pcg64 &r) {
+    const u128 MULT = (((u128)0x2360ED051FC65DA4ULL) << 64) | (u128)0x4385DF649FCCF645ULL;
+    u128 st = (((u128)r.sh) << 64) | r.sl;
+    u128 inc = (((u128)r.ih) << 64) | r.il;
+    st = st * MULT + inc;
+    r.sh = (uint64_t)(st >> 64);
+    r.sl = (uint64_t)st;
+    uint64_t x = r.sh ^ r.sl;
+    unsigned rot = (unsigned)(r.sh >> 58);
+    return (x >> rot) | (x << ((-rot) & 63));
+}
+
+__device__ __forceinline__ double pcg_next_double(Pcg64 &r) {
+    return (double)(pcg_next64(r) >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// Generator.standard_normal()
+__device__ inline double rng_std_normal(Pcg64 &g) {
+    const double ZIG_R = 3.6541528853610088, ZIG_INV_R = 0.27366123732975828;
+    for (;;) {
+        uint64_t r = pcg_next64(g);
+        int idx = (int)(r & 0xff);
+        r >>= 8;
+        int sign = (int)(r & 1);
+        uint64_t rabs = (r >> 1) & 0x000fffffffffffffULL;
+        double x = (double)rabs * KLHR_ZIG_WI[idx];
+        if (sign) x = -x;
+        if (rabs < KLHR_ZIG_KI[idx]) return x;          // ~98.8 % of draws
+        if (idx == 0) {
+            for (;;) {
+                double xx = -ZIG_INV_R * log1p(-pcg_next_double(g));
+                double yy = -log1p(-pcg_next_double(g));
+                if (yy + yy > xx * xx) return ((rabs >> 8) & 1) ? -(ZIG_R + xx) : ZIG_R + xx;
+            }
+        } else {
+            if (((KLHR_ZIG_FI[idx - 1] - KLHR_ZIG_FI[idx]) * pcg_next_double(g) + KLHR_ZIG_FI[idx]) < exp(-0.5 * x * x))
+                return x;
+        }
+    }
+}
+
+// Generator.uniform() == 0.0 + (1.0 - 0.0) * next_double
+__device__ __forceinline__ double rng_uniform(Pcg64 &g) { return pcg_next_double(g); }
+
+}  // namespace klhr

@@ -1,0 +1,623 @@
+// klhr_api.hip — host side of libklhr_hip.so: the C ABI declared in include/klhr.h.
+//
+// Owns all device memory of a sampler handle (chain-major SoA in HBM), one HIP stream per handle, and
+// launches the gfx950 kernels of klhr_kernels.hpp.  No PyTorch, no CPU fallback: every compute entry
+// point fails with KLHR_ERR_HIP when the device is unusable.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "klhr_kernels.hpp"
+
+using namespace klhr;
+
+static thread_local std::string g_create_err;
+
+struct klhr_sampler {
+    klhr_config cfg{};
+    int C = 0, D = 0, ncol = 0, S = 0, n_model = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timing_pending = false;
+    double last_ms = 0;
+    int last_launches = 0;
+    bool seeded = false;
+    std::string err;
+    KParams kp{};
+    double *d_aux = nullptr;
+    double *d_draws = nullptr;
+    size_t draws_cap = 0;          // bytes
+    int64_t draws_iters = 0;       // iterations recorded by the last recording call
+    std::vector<void *> allocs;
+};
+
+#define HIPCHECK(s, call)                                                                                  \
+    do {                                                                                                   \
+        hipError_t _e = (call);                                                                            \
+        if (_e != hipSuccess) {                                                                            \
+            char _b[512];                                                                                  \
+            snprintf(_b, sizeof _b, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+            (s)->err = _b;                                                                                 \
+            return KLHR_ERR_HIP;                                                                           \
+        }                                                                                                  \
+    } while (0)
+
+// ---- NumPy SeedSequence(seed).generate_state(4, uint64) -> PCG64 (numpy/random/bit_generator.pyx, _pcg64.pyx)
+extern "C" void klhr_seed_state(uint64_t seed, uint64_t out4[4]) {
+    const uint32_t INIT_A = 0x43b0d7e5u, MULT_A = 0x931e8875u, INIT_B = 0x8b51f9ddu, MULT_B = 0x58f38dedu;
+    const uint32_t MIX_L = 0xca01f9ddu, MIX_R = 0x4973f715u;
+    uint32_t entropy[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    const int n_entropy = entropy[1] ? 2 : 1;
+    uint32_t hash_const = INIT_A;
+    auto hashmix = [&](uint32_t v) {
+        v ^= hash_const;
+        hash_const *= MULT_A;
+        v *= hash_const;
+        v ^= v >> 16;
+        return v;
+    };
+    auto mix = [&](uint32_t x, uint32_t y) {
+        uint32_t r = MIX_L * x - MIX_R * y;
+        r ^= r >> 16;
+        return r;
+    };
+    uint32_t pool[4];
+    for (int i = 0; i < 4; i++) pool[i] = hashmix(i < n_entropy ? entropy[i] : 0u);
+    for (int src = 0; src < 4; src++)
+        for (int dst = 0; dst < 4; dst++)
+            if (src != dst) pool[dst] = mix(pool[dst], hashmix(pool[src]));
+    uint32_t words[8];
+    uint32_t hb = INIT_B;
+    for (int i = 0; i < 8; i++) {
+        uint32_t v = pool[i & 3];
+        v ^= hb;
+        hb *= MULT_B;
+        v *= hb;
+        v ^= v >> 16;
+        words[i] = v;
+    }
+    uint64_t q[4];
+    for (int i = 0; i < 4; i++) q[i] = (uint64_t)words[2 * i] | ((uint64_t)words[2 * i + 1] << 32);
+    typedef unsigned __int128 u128;
+    const u128 MULT = (((u128)0x2360ED051FC65DA4ULL) << 64) | (u128)0x4385DF649FCCF645ULL;
+    const u128 initstate = ((u128)q[0] << 64) | q[1], initseq = ((u128)q[2] << 64) | q[3];
+    u128 inc = (initseq << 1) | 1, state = 0;
+    state = state * MULT + inc;
+    state += initstate;
+    state = state * MULT + inc;
+    out4[0] = (uint64_t)(state >> 64);
+    out4[1] = (uint64_t)state;
+    out4[2] = (uint64_t)(inc >> 64);
+    out4[3] = (uint64_t)inc;
+}
+
+// WindowedAdaptation._calculate_windows (windowedadaptation.py:12-28)
+extern "C" int klhr_window_closures(int64_t warmup, int64_t windowsize, int64_t windowscale, int64_t *out, int cap) {
+    int n = 0;
+    if (!(warmup > windowsize)) return 0;
+    int64_t ws = windowsize, close = windowsize;
+    while (close <= warmup) {
+        if (n < cap && out) out[n] = close;
+        n++;
+        if (close == warmup) break;
+        ws *= windowscale;
+        int64_t next = close + ws;
+        close = (close + windowscale * ws >= warmup) ? warmup : next;
+    }
+    return n;
+}
+
+extern "C" int klhr_abi_version(void) { return KLHR_ABI_VERSION; }
+extern "C" const char *klhr_last_error(const klhr_sampler *s) { return s ? s->err.c_str() : g_create_err.c_str(); }
+extern "C" int klhr_dim(const klhr_sampler *s) { return s ? s->D : KLHR_ERR_ARG; }
+extern "C" int klhr_chains(const klhr_sampler *s) { return s ? s->C : KLHR_ERR_ARG; }
+
+template <class T>
+static int dalloc(klhr_sampler *s, T **p, size_t n) {
+    void *q = nullptr;
+    HIPCHECK(s, hipMalloc(&q, n * sizeof(T) ? n * sizeof(T) : 8));
+    s->allocs.push_back(q);
+    *p = (T *)q;
+    return 0;
+}
+
+static int reset_state(klhr_sampler *s) {
+    KParams &k = s->kp;
+    const size_t C = s->C, D = s->D, nc = s->ncol, J = s->cfg.J;
+    std::vector<double> ones(C * D, 1.0);
+    std::vector<int> ident(C * D);
+    for (size_t c = 0; c < C; c++)
+        for (size_t i = 0; i < D; i++) ident[c * D + i] = (int)i;
+    HIPCHECK(s, hipMemcpyAsync(k.cov, ones.data(), C * D * 8, hipMemcpyHostToDevice, s->stream));
+    HIPCHECK(s, hipMemcpyAsync(k.rank, ident.data(), C * D * 4, hipMemcpyHostToDevice, s->stream));
+    HIPCHECK(s, hipMemcpyAsync(k.eigvals, ones.data(), C * nc * 8 <= C * D * 8 ? C * nc * 8 : 0, hipMemcpyHostToDevice, s->stream));
+    HIPCHECK(s, hipMemsetAsync(k.theta, 0, C * D * 8, s->stream));
+    HIPCHECK(s, hipMemsetAsync(k.mean, 0, C * D * 8, s->stream));
+    HIPCHECK(s, hipMemsetAsync(k.eigvecs, 0, C * D * nc * 8, s->stream));
+    HIPCHECK(s, hipMemsetAsync(k.om_m, 0, C * D * 8, s->stream));
+    HIPCHECK(s, hipMemsetAsync(k.om_v, 0, C * D * 8, s->stream));
+    if (k.omd_m) {
+        HIPCHECK(s, hipMemsetAsync(k.omd_m, 0, C * D * 8, s->stream));
+        HIPCHECK(s, hipMemsetAsync(k.omd_v, 0, C * D * 8, s->stream));
+    }
+    HIPCHECK(s, hipMemsetAsync(k.pca_v, 0, C * D * J * 8, s->stream));
+    HIPCHECK(s, hipMemsetAsync(k.acc, 0, C * 8, s->stream));
+    HIPCHECK(s, hipMemsetAsync(k.counters, 0, C * 4 * 8, s->stream));
+    HIPCHECK(s, hipMemsetAsync(k.grad_evals, 0, C * 8, s->stream));
+    HIPCHECK(s, hipMemsetAsync(k.status, 0, C * 4, s->stream));
+    HIPCHECK(s, hipMemsetAsync(k.rng, 0, C * 4 * 8, s->stream));
+    HIPCHECK(s, hipMemsetAsync(k.d_rho, 0, C * D * 8, s->stream));
+    HIPCHECK(s, hipMemsetAsync(k.d_eta, 0, C * 4 * 8, s->stream));
+    HIPCHECK(s, hipMemsetAsync(k.d_diag, 0, C * KLHR_NDIAG * 8, s->stream));
+    HIPCHECK(s, hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, size_t n_model_data, klhr_sampler **out) {
+    if (out) *out = nullptr;
+    auto fail = [&](const char *m) { g_create_err = m; return KLHR_ERR_ARG; };
+    if (!cfg || !out || cfg->struct_size != sizeof(klhr_config)) return fail("klhr_create: bad config struct");
+    if (cfg->N != 8) return fail("klhr_create: this build maps one lane per quadrature node and supports N == 8 only");
+    if (cfg->J < 1 || cfg->J > 3) return fail("klhr_create: need 1 <= J <= 3");
+    if (cfg->overrelaxed) return fail("klhr_create: overrelaxed=True is not implemented (reference uses SciPy's unseeded global RNG)");
+    if (cfg->chains < 1) return fail("klhr_create: chains < 1");
+    if (!model_data || n_model_data < 1 || !cfg->quad_x || !cfg->quad_w || !cfg->quad_asinh_x) return fail("klhr_create: null data");
+    int D = 0, n = 0;
+    std::vector<double> aux;
+    switch (cfg->model_id) {
+    case KLHR_MODEL_FUNNEL: n = (int)model_data[0]; D = n + 1; break;
+    case KLHR_MODEL_NORMAL: D = (int)model_data[0]; break;
+    case KLHR_MODEL_ILL_NORMAL:
+        D = (int)model_data[0];
+        for (int i = 0; i < D; i++) aux.push_back(1.0 / ((double)(i + 1) / std::sqrt((double)D)));
+        break;
+    case KLHR_MODEL_GLMM_POISSON:
+        n = (int)model_data[0];
+        if (n < 1 || n_model_data < (size_t)(1 + 2 * n)) return fail("klhr_create: glmm-poisson data too short");
+        D = n + 5;
+        aux.resize(4 * (size_t)n);
+        for (int i = 0; i < n; i++) {
+            double y = model_data[1 + i];
+            aux[i] = y; aux[n + i] = y * y; aux[2 * n + i] = y * y * y; aux[3 * n + i] = model_data[1 + n + i];
+        }
+        break;
+    default: return fail("klhr_create: unknown model_id");
+    }
+    if (D < 1) return fail("klhr_create: model dimension < 1");
+
+    klhr_sampler *s = new klhr_sampler();
+    s->cfg = *cfg;
+    s->cfg.quad_x = s->cfg.quad_w = s->cfg.quad_asinh_x = nullptr;
+    s->C = cfg->chains; s->D = D; s->ncol = cfg->J + (cfg->eigen_method_one ? 1 : 0);
+    // LDS per chain: D double2 (theta, rho) + D doubles scratch; stride staggered over banks (S % 32 == 4)
+    int S = 3 * D;
+    while (S % 32 != 4) S++;
+    s->S = S;
+    auto bail = [&](int rc) { g_create_err = s->err; klhr_destroy(s); return rc; };
+    {
+        hipError_t e = hipSetDevice(cfg->device);
+        if (e != hipSuccess) { s->err = std::string("hipSetDevice failed: ") + hipGetErrorString(e); return bail(KLHR_ERR_HIP); }
+    }
+    if ((size_t)8 * S * 8 > 64 * 1024) { s->err = "klhr_create: model dimension too large for the LDS layout (D <= 1300)"; return bail(KLHR_ERR_ARG); }
+#define TRY(x) do { int _rc = (x); if (_rc) return bail(_rc); } while (0)
+    auto hip_try = [&](hipError_t e, const char *what) { if (e != hipSuccess) { s->err = std::string(what) + ": " + hipGetErrorString(e); return (int)KLHR_ERR_HIP; } return 0; };
+    TRY(hip_try(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking), "hipStreamCreate"));
+    TRY(hip_try(hipEventCreate(&s->ev0), "hipEventCreate"));
+    TRY(hip_try(hipEventCreate(&s->ev1), "hipEventCreate"));
+    KParams &k = s->kp;
+    const size_t C = s->C, nc = s->ncol, J = cfg->J;
+    k.C = s->C; k.D = D; k.S = S; k.ncol = s->ncol; k.J = cfg->J;
+    k.flags = (cfg->scale_dir_cov ? FLAG_SCALE_DIR_COV : 0) | (cfg->eigen_method_one ? FLAG_EIGEN_ONE : 0);
+    k.tol = cfg->tol; k.scale_clip = cfg->scale_clip; k.initscale = cfg->initscale; k.l = cfg->l;
+    for (int i = 0; i < 8; i++) { k.xq[i] = cfg->quad_x[i]; k.wq[i] = cfg->quad_w[i]; k.asx[i] = cfg->quad_asinh_x[i]; }
+    TRY(dalloc(s, &s->d_aux, aux.size()));
+    if (!aux.empty()) TRY(hip_try(hipMemcpy(s->d_aux, aux.data(), aux.size() * 8, hipMemcpyHostToDevice), "hipMemcpy aux"));
+    k.md.aux = s->d_aux; k.md.D = D; k.md.n = n;
+    TRY(dalloc(s, &k.theta, C * D)); TRY(dalloc(s, &k.rng, C * 4)); TRY(dalloc(s, &k.mean, C * D)); TRY(dalloc(s, &k.cov, C * D));
+    TRY(dalloc(s, &k.eigvecs, C * D * nc)); TRY(dalloc(s, &k.eigvals, C * nc > C * D ? C * nc : C * D));
+    TRY(dalloc(s, &k.om_m, C * D)); TRY(dalloc(s, &k.om_v, C * D));
+    if (cfg->scale_dir_cov) { TRY(dalloc(s, &k.omd_m, C * D)); TRY(dalloc(s, &k.omd_v, C * D)); }
+    TRY(dalloc(s, &k.pca_v, C * D * J)); TRY(dalloc(s, &k.acc, C)); TRY(dalloc(s, &k.rank, C * D));
+    TRY(dalloc(s, &k.counters, C * 4)); TRY(dalloc(s, &k.grad_evals, C)); TRY(dalloc(s, &k.status, C));
+    TRY(dalloc(s, &k.d_rho, C * D)); TRY(dalloc(s, &k.d_eta, C * 4)); TRY(dalloc(s, &k.d_diag, C * KLHR_NDIAG));
+    k.warmup = cfg->warmup; k.windowsize = cfg->windowsize;
+    int64_t cl[40];
+    int ncl = klhr_window_closures(cfg->warmup, cfg->windowsize, cfg->windowscale, cl, 40);
+    if (ncl > 40) { s->err = "klhr_create: more than 40 adaptation windows"; return bail(KLHR_ERR_ARG); }
+    k.nclos = ncl;
+    for (int i = 0; i < ncl; i++) k.closures[i] = cl[i];
+    TRY(reset_state(s));
+#undef TRY
+    *out = s;
+    return KLHR_OK;
+}
+
+extern "C" void klhr_destroy(klhr_sampler *s) {
+    if (!s) return;
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    for (void *p : s->allocs) (void)hipFree(p);
+    if (s->d_draws) (void)hipFree(s->d_draws);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+extern "C" int klhr_sync(klhr_sampler *s) {
+    if (!s) return KLHR_ERR_ARG;
+    HIPCHECK(s, hipStreamSynchronize(s->stream));
+    return KLHR_OK;
+}
+
+// ---- launches ------------------------------------------------------------------------------------
+static int launch_iter(klhr_sampler *s, const KParams &kp) {
+    const dim3 grid((kp.C + 7) / 8), block(64);
+    const size_t lds = (size_t)8 * kp.S * sizeof(double);
+    switch (s->cfg.model_id) {
+    case KLHR_MODEL_FUNNEL: hipLaunchKernelGGL(klhr_iter_kernel<MODEL_FUNNEL>, grid, block, lds, s->stream, kp); break;
+    case KLHR_MODEL_ILL_NORMAL: hipLaunchKernelGGL(klhr_iter_kernel<MODEL_ILL_NORMAL>, grid, block, lds, s->stream, kp); break;
+    case KLHR_MODEL_GLMM_POISSON: hipLaunchKernelGGL(klhr_iter_kernel<MODEL_GLMM_POISSON>, grid, block, lds, s->stream, kp); break;
+    default: hipLaunchKernelGGL(klhr_iter_kernel<MODEL_NORMAL>, grid, block, lds, s->stream, kp); break;
+    }
+    HIPCHECK(s, hipGetLastError());
+    return 0;
+}
+
+static int ensure_draws(klhr_sampler *s, int64_t n_iters) {
+    size_t need = (size_t)n_iters * s->C * s->D * 8;
+    if (need > s->draws_cap) {
+        if (s->d_draws) { HIPCHECK(s, hipStreamSynchronize(s->stream)); HIPCHECK(s, hipFree(s->d_draws)); s->d_draws = nullptr; s->draws_cap = 0; }
+        HIPCHECK(s, hipMalloc((void **)&s->d_draws, need));
+        s->draws_cap = need;
+    }
+    return 0;
+}
+
+static int run_phases(klhr_sampler *s, int phases, int64_t n_iters, int record_draws, int record_diag) {
+    if (!s->seeded && (phases & (PH_DIR | PH_FIT | PH_MH))) { s->err = "klhr: chains are not seeded (call klhr_seed or set RNG/theta state)"; return KLHR_ERR_STATE; }
+    HIPCHECK(s, hipSetDevice(s->cfg.device));
+    if (record_draws) { int rc = ensure_draws(s, n_iters); if (rc) return rc; s->draws_iters = n_iters; }
+    // chunk the iterations so that a single launch stays short; chain state persists in HBM between launches
+    const int64_t chunk_max = 64;
+    HIPCHECK(s, hipEventRecord(s->ev0, s->stream));
+    int launches = 0;
+    for (int64_t done = 0; done < n_iters; done += chunk_max) {
+        KParams kp = s->kp;
+        kp.phases = phases;
+        kp.n_iters = (int)((n_iters - done) < chunk_max ? (n_iters - done) : chunk_max);
+        if (record_diag) kp.flags |= FLAG_DIAG;
+        kp.draws = record_draws ? s->d_draws + (size_t)done * s->C * s->D : nullptr;
+        int rc = launch_iter(s, kp);
+        if (rc) return rc;
+        launches++;
+    }
+    HIPCHECK(s, hipEventRecord(s->ev1, s->stream));
+    s->timing_pending = true;
+    s->last_launches = launches;
+    return KLHR_OK;
+}
+
+extern "C" int klhr_step(klhr_sampler *s, int64_t n_iters, int record_draws, int record_diag) {
+    if (!s || n_iters < 0) return KLHR_ERR_ARG;
+    if (n_iters == 0) return KLHR_OK;
+    return run_phases(s, PH_ALL, n_iters, record_draws, record_diag);
+}
+
+extern "C" int klhr_last_step_timing(klhr_sampler *s, double *kernel_ms, int *n_launches) {
+    if (!s) return KLHR_ERR_ARG;
+    if (s->timing_pending) {
+        HIPCHECK(s, hipEventSynchronize(s->ev1));
+        float ms = 0;
+        HIPCHECK(s, hipEventElapsedTime(&ms, s->ev0, s->ev1));
+        s->last_ms = ms;
+        s->timing_pending = false;
+    }
+    if (kernel_ms) *kernel_ms = s->last_ms;
+    if (n_launches) *n_launches = s->last_launches;
+    return KLHR_OK;
+}
+
+extern "C" int klhr_get_draws(klhr_sampler *s, double *host_out, int64_t first_iter, int64_t n_iters) {
+    if (!s || !host_out || first_iter < 0 || n_iters < 0 || first_iter + n_iters > s->draws_iters) return KLHR_ERR_ARG;
+    const size_t per = (size_t)s->C * s->D;
+    HIPCHECK(s, hipMemcpyAsync(host_out, s->d_draws + (size_t)first_iter * per, (size_t)n_iters * per * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHECK(s, hipStreamSynchronize(s->stream));
+    return KLHR_OK;
+}
+
+// ---- seeding -------------------------------------------------------------------------------------
+template <class F>
+static int launch_by_model(klhr_sampler *s, F f) {
+    switch (s->cfg.model_id) {
+    case KLHR_MODEL_FUNNEL: f(std::integral_constant<int, MODEL_FUNNEL>()); break;
+    case KLHR_MODEL_ILL_NORMAL: f(std::integral_constant<int, MODEL_ILL_NORMAL>()); break;
+    case KLHR_MODEL_GLMM_POISSON: f(std::integral_constant<int, MODEL_GLMM_POISSON>()); break;
+    default: f(std::integral_constant<int, MODEL_NORMAL>()); break;
+    }
+    HIPCHECK(s, hipGetLastError());
+    return 0;
+}
+
+static int upload_seeds(klhr_sampler *s, const uint64_t *seeds) {
+    std::vector<uint64_t> st((size_t)s->C * 4);
+    for (int c = 0; c < s->C; c++) klhr_seed_state(seeds[c], &st[(size_t)c * 4]);
+    HIPCHECK(s, hipMemcpyAsync(s->kp.rng, st.data(), st.size() * 8, hipMemcpyHostToDevice, s->stream));
+    HIPCHECK(s, hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+extern "C" int klhr_seed(klhr_sampler *s, const uint64_t *seeds, int theta_given) {
+    if (!s || !seeds) return KLHR_ERR_ARG;
+    HIPCHECK(s, hipSetDevice(s->cfg.device));
+    int rc = reset_state(s);
+    if (rc) return rc;
+    rc = upload_seeds(s, seeds);
+    if (rc) return rc;
+    const int bs = 64;
+    const dim3 grid((s->C + bs - 1) / bs), block(bs);
+    KParams kp = s->kp;
+    const int mt = s->cfg.max_init_tries;
+    rc = launch_by_model(s, [&](auto M) { hipLaunchKernelGGL(klhr_init_kernel<decltype(M)::value>, grid, block, 0, s->stream, kp, theta_given, mt); });
+    if (rc) return rc;
+    std::vector<int> st(s->C);
+    HIPCHECK(s, hipMemcpyAsync(st.data(), s->kp.status, (size_t)s->C * 4, hipMemcpyDeviceToHost, s->stream));
+    HIPCHECK(s, hipStreamSynchronize(s->stream));
+    s->seeded = true;
+    for (int c = 0; c < s->C; c++)
+        if (st[c] & 1) { s->err = "klhr_seed: failed to initialize (some chain found no finite log density within max_init_tries)"; return KLHR_ERR_INIT; }
+    return KLHR_OK;
+}
+
+// ---- pieces --------------------------------------------------------------------------------------
+static int h2d(klhr_sampler *s, void *dst, const void *src, size_t bytes) {
+    HIPCHECK(s, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s->stream));
+    HIPCHECK(s, hipStreamSynchronize(s->stream));   // the caller's buffer may be pageable and reused immediately
+    return 0;
+}
+static int d2h(klhr_sampler *s, void *dst, const void *src, size_t bytes) {
+    HIPCHECK(s, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s->stream));
+    HIPCHECK(s, hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+extern "C" int klhr_random_direction(klhr_sampler *s, double *rho_out) {
+    if (!s) return KLHR_ERR_ARG;
+    int rc = run_phases(s, PH_DIR, 1, 0, 1);
+    if (rc) return rc;
+    return rho_out ? d2h(s, rho_out, s->kp.d_rho, (size_t)s->C * s->D * 8) : klhr_sync(s);
+}
+
+extern "C" int klhr_fit(klhr_sampler *s, const double *rho, double *eta_out) {
+    if (!s || !rho) return KLHR_ERR_ARG;
+    int rc = h2d(s, s->kp.d_rho, rho, (size_t)s->C * s->D * 8);
+    if (rc) return rc;
+    rc = run_phases(s, PH_FIT, 1, 0, 1);
+    if (rc) return rc;
+    return eta_out ? d2h(s, eta_out, s->kp.d_eta, (size_t)s->C * 4 * 8) : klhr_sync(s);
+}
+
+extern "C" int klhr_metropolis(klhr_sampler *s, const double *eta, const double *rho) {
+    if (!s || !eta || !rho) return KLHR_ERR_ARG;
+    int rc = h2d(s, s->kp.d_rho, rho, (size_t)s->C * s->D * 8);
+    if (rc) return rc;
+    rc = h2d(s, s->kp.d_eta, eta, (size_t)s->C * 4 * 8);
+    if (rc) return rc;
+    rc = run_phases(s, PH_MH, 1, 0, 1);
+    if (rc) return rc;
+    return klhr_sync(s);
+}
+
+extern "C" int klhr_adapt(klhr_sampler *s) {
+    if (!s) return KLHR_ERR_ARG;
+    int rc = run_phases(s, PH_ADAPT, 1, 0, 0);
+    if (rc) return rc;
+    return klhr_sync(s);
+}
+
+static int probe(klhr_sampler *s, int phase, const double *eta_or_t, int eta_cols, const double *rho, double *out, int out_cols) {
+    const size_t C = s->C;
+    std::vector<double> e4(C * 4, 0.0);
+    for (size_t c = 0; c < C; c++)
+        for (int k = 0; k < eta_cols; k++) e4[c * 4 + k] = eta_or_t[c * eta_cols + k];
+    int rc = h2d(s, s->kp.d_rho, rho, C * s->D * 8);
+    if (rc) return rc;
+    rc = h2d(s, s->kp.d_eta, e4.data(), C * 4 * 8);
+    if (rc) return rc;
+    rc = run_phases(s, phase, 1, 0, 0);
+    if (rc) return rc;
+    std::vector<double> dg(C * KLHR_NDIAG);
+    rc = d2h(s, dg.data(), s->kp.d_diag, C * KLHR_NDIAG * 8);
+    if (rc) return rc;
+    for (size_t c = 0; c < C; c++)
+        for (int k = 0; k < out_cols; k++) out[c * out_cols + k] = dg[c * KLHR_NDIAG + k];
+    return KLHR_OK;
+}
+
+extern "C" int klhr_kl_eval(klhr_sampler *s, const double *eta, const double *rho, double *value_out, double *grad_out) {
+    if (!s || !eta || !rho || !value_out || !grad_out) return KLHR_ERR_ARG;
+    std::vector<double> o((size_t)s->C * 5);
+    int rc = probe(s, PH_KL, eta, 4, rho, o.data(), 5);
+    if (rc) return rc;
+    for (int c = 0; c < s->C; c++) {
+        value_out[c] = o[(size_t)c * 5];
+        for (int k = 0; k < 4; k++) grad_out[(size_t)c * 4 + k] = o[(size_t)c * 5 + 1 + k];
+    }
+    return KLHR_OK;
+}
+
+extern "C" int klhr_line_eval(klhr_sampler *s, const double *t, const double *rho, double *out2) {
+    if (!s || !t || !rho || !out2) return KLHR_ERR_ARG;
+    return probe(s, PH_LINE, t, 1, rho, out2, 2);
+}
+
+extern "C" int klhr_log_density_gradient(klhr_sampler *s, const double *thetas, int64_t n, double *lp_out, double *grad_out) {
+    if (!s || !thetas || !lp_out || n < 0) return KLHR_ERR_ARG;
+    if (n == 0) return KLHR_OK;
+    HIPCHECK(s, hipSetDevice(s->cfg.device));
+    double *d_th = nullptr, *d_lp = nullptr, *d_g = nullptr;
+    const size_t D = s->D;
+    HIPCHECK(s, hipMalloc((void **)&d_th, (size_t)n * D * 8));
+    HIPCHECK(s, hipMalloc((void **)&d_lp, (size_t)n * 8));
+    if (grad_out) HIPCHECK(s, hipMalloc((void **)&d_g, (size_t)n * D * 8));
+    int rc = h2d(s, d_th, thetas, (size_t)n * D * 8);
+    if (!rc) {
+        const int bs = 64;
+        const dim3 grid((unsigned)((n + bs - 1) / bs)), block(bs);
+        ModelData md = s->kp.md;
+        rc = launch_by_model(s, [&](auto M) { hipLaunchKernelGGL(klhr_logp_kernel<decltype(M)::value>, grid, block, 0, s->stream, md, d_th, (long long)n, d_lp, d_g); });
+    }
+    if (!rc) rc = d2h(s, lp_out, d_lp, (size_t)n * 8);
+    if (!rc && grad_out) rc = d2h(s, grad_out, d_g, (size_t)n * D * 8);
+    (void)hipFree(d_th); (void)hipFree(d_lp); if (d_g) (void)hipFree(d_g);
+    return rc;
+}
+
+extern "C" int klhr_primitives(klhr_sampler *s, const double *x, const double *eta, int64_t n, double *out12) {
+    if (!s || !x || !eta || !out12 || n < 0) return KLHR_ERR_ARG;
+    if (n == 0) return KLHR_OK;
+    HIPCHECK(s, hipSetDevice(s->cfg.device));
+    double *d_x = nullptr, *d_e = nullptr, *d_o = nullptr;
+    HIPCHECK(s, hipMalloc((void **)&d_x, (size_t)n * 8));
+    HIPCHECK(s, hipMalloc((void **)&d_e, (size_t)n * 32));
+    HIPCHECK(s, hipMalloc((void **)&d_o, (size_t)n * 96));
+    int rc = h2d(s, d_x, x, (size_t)n * 8);
+    if (!rc) rc = h2d(s, d_e, eta, (size_t)n * 32);
+    if (!rc) {
+        const int bs = 64;
+        hipLaunchKernelGGL(klhr_prim_kernel, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, s->stream, d_x, d_e, (long long)n, s->cfg.tol, s->cfg.scale_clip, d_o);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { s->err = hipGetErrorString(e); rc = KLHR_ERR_HIP; }
+    }
+    if (!rc) rc = d2h(s, out12, d_o, (size_t)n * 96);
+    (void)hipFree(d_x); (void)hipFree(d_e); (void)hipFree(d_o);
+    return rc;
+}
+
+// ---- state access --------------------------------------------------------------------------------
+static bool field_info(klhr_sampler *s, int field, void **ptr, size_t *bytes) {
+    const size_t C = s->C, D = s->D, nc = s->ncol, J = s->cfg.J;
+    KParams &k = s->kp;
+    switch (field) {
+    case KLHR_F_THETA: *ptr = k.theta; *bytes = C * D * 8; return true;
+    case KLHR_F_RNG: *ptr = k.rng; *bytes = C * 32; return true;
+    case KLHR_F_MEAN: *ptr = k.mean; *bytes = C * D * 8; return true;
+    case KLHR_F_COV: *ptr = k.cov; *bytes = C * D * 8; return true;
+    case KLHR_F_EIGVECS: *ptr = k.eigvecs; *bytes = C * D * nc * 8; return true;
+    case KLHR_F_EIGVALS: *ptr = k.eigvals; *bytes = C * nc * 8; return true;
+    case KLHR_F_OM_M: *ptr = k.om_m; *bytes = C * D * 8; return true;
+    case KLHR_F_OM_V: *ptr = k.om_v; *bytes = C * D * 8; return true;
+    case KLHR_F_OMD_M: *ptr = k.omd_m; *bytes = C * D * 8; return k.omd_m != nullptr;
+    case KLHR_F_OMD_V: *ptr = k.omd_v; *bytes = C * D * 8; return k.omd_v != nullptr;
+    case KLHR_F_PCA_V: *ptr = k.pca_v; *bytes = C * D * J * 8; return true;
+    case KLHR_F_COUNTERS: *ptr = k.counters; *bytes = C * 32; return true;
+    case KLHR_F_ACC: *ptr = k.acc; *bytes = C * 8; return true;
+    case KLHR_F_GRAD_EVALS: *ptr = k.grad_evals; *bytes = C * 8; return true;
+    case KLHR_F_RHO: *ptr = k.d_rho; *bytes = C * D * 8; return true;
+    case KLHR_F_ETA: *ptr = k.d_eta; *bytes = C * 32; return true;
+    case KLHR_F_DIAG: *ptr = k.d_diag; *bytes = C * KLHR_NDIAG * 8; return true;
+    case KLHR_F_STATUS: *ptr = k.status; *bytes = C * 4; return true;
+    }
+    return false;
+}
+
+extern "C" int klhr_get_state(klhr_sampler *s, int field, void *host_out, size_t bytes) {
+    if (!s || !host_out) return KLHR_ERR_ARG;
+    void *p; size_t nb;
+    if (!field_info(s, field, &p, &nb) || nb != bytes) { s->err = "klhr_get_state: unknown field or size mismatch"; return KLHR_ERR_ARG; }
+    return d2h(s, host_out, p, nb);
+}
+
+extern "C" int klhr_set_state(klhr_sampler *s, int field, const void *host_in, size_t bytes) {
+    if (!s || !host_in) return KLHR_ERR_ARG;
+    void *p; size_t nb;
+    if (!field_info(s, field, &p, &nb) || nb != bytes) { s->err = "klhr_set_state: unknown field or size mismatch"; return KLHR_ERR_ARG; }
+    int rc = h2d(s, p, host_in, nb);
+    if (rc) return rc;
+    if (field == KLHR_F_COV) {
+        const int bs = 64;
+        hipLaunchKernelGGL(klhr_rank_kernel, dim3((s->C + bs - 1) / bs), dim3(bs), 0, s->stream, s->kp.cov, s->kp.rank, s->C, s->D);
+        HIPCHECK(s, hipGetLastError());
+        HIPCHECK(s, hipStreamSynchronize(s->stream));
+    }
+    if (field == KLHR_F_RNG || field == KLHR_F_THETA) s->seeded = true;
+    return KLHR_OK;
+}
+
+// ---- MH comparator ---------------------------------------------------------------------------------
+extern "C" int klhr_mh_seed(klhr_sampler *s, const uint64_t *seeds) {
+    if (!s || !seeds) return KLHR_ERR_ARG;
+    HIPCHECK(s, hipSetDevice(s->cfg.device));
+    int rc = reset_state(s);
+    if (rc) return rc;
+    rc = upload_seeds(s, seeds);
+    if (rc) return rc;
+    const int bs = 64;
+    const dim3 grid((s->C + bs - 1) / bs), block(bs);
+    KParams kp = s->kp;
+    kp.n_iters = 0; kp.draws = nullptr;
+    rc = launch_by_model(s, [&](auto M) { hipLaunchKernelGGL(klhr_mh_kernel<decltype(M)::value>, grid, block, 0, s->stream, kp, 0.0, 1); });
+    if (rc) return rc;
+    s->seeded = true;
+    return klhr_sync(s);
+}
+
+extern "C" int klhr_mh_step(klhr_sampler *s, double stepsize, int64_t n_iters, int record_draws) {
+    if (!s || n_iters < 0) return KLHR_ERR_ARG;
+    if (!s->seeded) { s->err = "klhr_mh_step: not seeded"; return KLHR_ERR_STATE; }
+    HIPCHECK(s, hipSetDevice(s->cfg.device));
+    if (record_draws) { int rc = ensure_draws(s, n_iters); if (rc) return rc; s->draws_iters = n_iters; }
+    const int bs = 64;
+    const dim3 grid((s->C + bs - 1) / bs), block(bs);
+    const int64_t chunk_max = 4096;
+    HIPCHECK(s, hipEventRecord(s->ev0, s->stream));
+    int launches = 0;
+    for (int64_t done = 0; done < n_iters; done += chunk_max) {
+        KParams kp = s->kp;
+        kp.n_iters = (int)((n_iters - done) < chunk_max ? (n_iters - done) : chunk_max);
+        kp.draws = record_draws ? s->d_draws + (size_t)done * s->C * s->D : nullptr;
+        int rc = launch_by_model(s, [&](auto M) { hipLaunchKernelGGL(klhr_mh_kernel<decltype(M)::value>, grid, block, 0, s->stream, kp, stepsize, 0); });
+        if (rc) return rc;
+        launches++;
+    }
+    HIPCHECK(s, hipEventRecord(s->ev1, s->stream));
+    s->timing_pending = true;
+    s->last_launches = launches;
+    return KLHR_OK;
+}
+
+// ---- pooled adaptation (extension) ------------------------------------------------------------------
+extern "C" int klhr_pool_stats(klhr_sampler *s, double *out, size_t n_out) {
+    if (!s || !out || n_out != (size_t)(1 + 2 * s->D)) return KLHR_ERR_ARG;
+    HIPCHECK(s, hipSetDevice(s->cfg.device));
+    double *d_o = nullptr;
+    HIPCHECK(s, hipMalloc((void **)&d_o, n_out * 8));
+    hipLaunchKernelGGL(klhr_pool_kernel, dim3(s->D), dim3(256), 0, s->stream, s->kp.om_m, s->kp.om_v, s->kp.counters, s->C, s->D, d_o);
+    int rc = 0;
+    { hipError_t e = hipGetLastError(); if (e != hipSuccess) { s->err = hipGetErrorString(e); rc = KLHR_ERR_HIP; } }
+    if (!rc) rc = d2h(s, out, d_o, n_out * 8);
+    (void)hipFree(d_o);
+    return rc;
+}
+
+extern "C" int klhr_pool_apply(klhr_sampler *s, const double *mean, const double *cov) {
+    if (!s || !mean || !cov) return KLHR_ERR_ARG;
+    HIPCHECK(s, hipSetDevice(s->cfg.device));
+    double *d_m = nullptr;
+    const size_t D = s->D;
+    HIPCHECK(s, hipMalloc((void **)&d_m, 2 * D * 8));
+    int rc = h2d(s, d_m, mean, D * 8);
+    if (!rc) rc = h2d(s, d_m + D, cov, D * 8);
+    if (!rc) {
+        const int bs = 64;
+        hipLaunchKernelGGL(klhr_pool_apply_kernel, dim3((s->C + bs - 1) / bs), dim3(bs), 0, s->stream, d_m, d_m + D, s->kp.mean, s->kp.cov, s->kp.rank, s->C, s->D);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { s->err = hipGetErrorString(e); rc = KLHR_ERR_HIP; }
+    }
+    if (!rc) rc = klhr_sync(s);
+    (void)hipFree(d_m);
+    return rc;
+}

@@ -1,0 +1,653 @@
+// klhr_kernels.hpp — gfx950 kernels of the many-chain KL Hit-and-Run sampler.
+//
+// Mapping of work to the machine ("octet per chain"):
+//   * one chain = 8 adjacent lanes (one lane per Gauss-Hermite node, N = 8); one 64-lane wavefront = 8 chains;
+//     one workgroup = one wavefront, so there is no inter-wave synchronisation anywhere;
+//   * a chain's (theta_i, rho_i) pairs live in LDS as double2 for the whole launch (one ds_read_b128 per
+//     coordinate per node evaluation, broadcast inside the octet, bank-staggered across octets);
+//   * RNG state, optimiser state and all scalars live in registers, replicated across the octet
+//     (identical bits in all 8 lanes: every reduction is a commutative butterfly);
+//   * the adaptation state (OnlineMoments, CCIPCA, published mean/cov/eigvecs) stays in HBM, touched once per
+//     iteration with lane-strided, chain-contiguous accesses;
+//   * a launch runs n_iters whole iterations; between two launches only HBM state survives.
+//
+// Control flow per iteration (klhr_sinh.py:262-289): direction -> [evaluation passes] -> MH -> adapt.
+// All 8 chains of a wavefront share every evaluation pass; SciPy's data-dependent optimiser control flow
+// happens between passes in opt_advance() (device_opt.hpp).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_models.hpp"
+#include "device_opt.hpp"
+#include "device_rng.hpp"
+#include "../../include/klhr.h"
+
+namespace klhr {
+
+enum { PH_DIR = 1, PH_FIT = 2, PH_MH = 4, PH_ADAPT = 8, PH_ALL = 15, PH_KL = 16, PH_LINE = 32 };
+enum { FLAG_SCALE_DIR_COV = 1, FLAG_EIGEN_ONE = 2, FLAG_DIAG = 4, FLAG_DRAWS = 8 };
+
+struct KParams {
+    int C, D, S, ncol, J, flags, phases, n_iters;
+    ModelData md;
+    double tol, scale_clip, initscale, l;
+    double xq[8], wq[8], asx[8];
+    double *theta;
+    uint64_t *rng;
+    double *mean, *cov, *eigvecs, *eigvals, *om_m, *om_v, *omd_m, *omd_v, *pca_v, *acc;
+    int *rank;
+    long long *counters;      // C×4: draw, om_N, pca_n, cidx
+    long long *grad_evals;
+    int *status;
+    double *d_rho, *d_eta, *d_diag;
+    double *draws;            // [n_iters][C][D] or nullptr
+    long long warmup, windowsize;
+    int nclos;
+    long long closures[40];
+};
+
+__device__ __forceinline__ double grp_sum8(double v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    return v;
+}
+
+// sinh-arcsinh helpers (klhr_sinh.py:78-84): s = exp(clip(eta1)) + tol, d = exp(clip(eta2)) + tol
+__device__ __forceinline__ void sa_unpack(const double *eta, double tol, double sc, double &m, double &s, double &d, double &e) {
+    m = eta[0];
+    s = exp(clipc(eta[1], sc)) + tol;
+    d = exp(clipc(eta[2], sc)) + tol;
+    e = eta[3];
+}
+// klhr_sinh.py:112-114
+__device__ inline double sa_T(double x, const double *eta, double tol, double sc) {
+    double m, s, d, e;
+    sa_unpack(eta, tol, sc, m, s, d, e);
+    return __dadd_rn(m, __dmul_rn(s, sinh(clipc((asinh(x) + e) / d, sc))));
+}
+// klhr_sinh.py:126-129
+__device__ inline double sa_T_inv(double x, const double *eta, double tol, double sc) {
+    double m, s, d, e;
+    sa_unpack(eta, tol, sc, m, s, d, e);
+    double z = (x - m) / s;
+    return sinh(clipc(d * asinh(z) - e, sc));
+}
+// klhr_sinh.py:230-240
+__device__ inline double sa_log_q(double x, const double *eta, double tol, double sc) {
+    double m, s, d, e;
+    sa_unpack(eta, tol, sc, m, s, d, e);
+    double z = (x - m) / s;
+    double u = clipc(d * asinh(z) - e, sc);
+    double ti = sinh(u);
+    double ld = -0.5 * ti * ti;
+    ld += log(cosh(u));
+    ld += eta[2] - eta[1];
+    ld -= 0.5 * log1p(z * z);
+    return ld;
+}
+
+// One objective evaluation for one chain, spread over its octet.
+//   n == 4: KL(eta = xt) value and gradient (klhr_sinh.py:163-176): lane j evaluates node j
+//   n == 1: (-logp, -grad.rho) at theta + xt[0]*rho (klhr_sinh.py:178-180), computed redundantly by the octet
+template <int MODEL>
+__device__ __forceinline__ void eval_objective(const KParams &p, const double2 *TR, int n, const double *xt, double asx_l,
+                                               double w_l, double &f, double *g) {
+    double t, a = 0, sh = 0, ch = 1, s_ = 0, invd = 0;
+    const double cl = (n == 4) ? p.scale_clip : INFINITY;
+    if (n == 4) {
+        s_ = exp(clipc(xt[1], p.scale_clip)) + p.tol;
+        double d_ = exp(clipc(xt[2], p.scale_clip)) + p.tol;
+        invd = 1.0 / d_;
+        a = (asx_l + xt[3]) * invd;
+        double ac = clipc(a, p.scale_clip);
+        sh = sinh(ac);
+        ch = cosh(ac);
+        t = xt[0] + s_ * sh;
+    } else {
+        t = xt[0];
+    }
+    double logp, gdot;
+    model_eval<MODEL>(p.md, [&](int i, double &xi, double &ri) { double2 v = TR[i]; ri = v.y; xi = fma(t, v.y, v.x); }, cl,
+                      NoSink(), logp, gdot);
+    if (n == 4) {
+        const double w = w_l;
+        const double th = sh / ch;
+        const double laj = (xt[2] - xt[1]) - log(ch);
+        const double wg = w * gdot;
+        double c0 = w * (laj - logp);
+        double c1 = -wg;
+        double c2 = -(wg * (s_ * sh)) - w;
+        double c3 = wg * (s_ * ch * a) + w * (1.0 + th * a);
+        double c4 = -(wg * (s_ * ch * invd)) - w * (th * invd);
+        f = grp_sum8(c0);
+        g[0] = grp_sum8(c1);
+        g[1] = grp_sum8(c2);
+        g[2] = grp_sum8(c3);
+        g[3] = grp_sum8(c4);
+    } else {
+        f = -logp;
+        g[0] = -gdot;
+        g[1] = g[2] = g[3] = 0.0;
+    }
+}
+
+// workgroup == one wavefront: LDS hand-offs between the lanes of an octet only need the wave's own LDS traffic
+// ordered (fence) and the compiler kept from moving code across (wave_barrier); no s_barrier is executed.
+#define KLHR_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); \
+                              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); } while (0)
+
+// ---- bit-exact (unfused, sequential) pieces: must round exactly like the NumPy expressions they restate
+#pragma clang fp contract(off)
+
+// klhr_sinh.py:203-213 + Generator.multivariate_normal(method='svd') rank rule.  Z must hold the D standard
+// normals in stream order.  Writes rho into TR[i].y.
+__device__ inline void direction_from_normals(const KParams &p, long long c, double2 *TR, const double *Z, int l8, double u_choice) {
+    const int D = p.D, nc = p.ncol;
+    const double *ev = p.eigvals + c * nc;
+    const double *evec = p.eigvecs + c * (long long)D * nc;
+    const double *cov = p.cov + c * (long long)D;
+    const int *rank = p.rank + c * (long long)D;
+    double pj[4] = {0, 0, 0, 0};
+    double sum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (j < nc) sum += ev[j];
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (j < nc) pj[j] = ev[j] / sum;
+    int pick = -1;
+    if (p.flags & FLAG_EIGEN_ONE) {
+        // rng.choice(n, p=p): cdf = cumsum(p); cdf /= cdf[-1]; searchsorted(cdf, random(), side='right')
+        double cdf[4], accu = 0, last = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { accu += pj[j]; cdf[j] = accu; if (j == nc - 1) last = accu; }
+        pick = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (j < nc && cdf[j] / last <= u_choice) pick = j + 1;
+        if (pick >= nc) pick = nc - 1;
+    }
+    double nn = 0;
+    for (int i = 0; i < D; i++) {
+        double m = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (j < nc) {
+                double e = evec[i * nc + j];
+                if (pick >= 0) { if (j == pick) m = e; }
+                else m += pj[j] * e;
+            }
+        }
+        double r = m + sqrt(cov[i]) * Z[rank[i]];
+        nn += (r + p.tol) * (r + p.tol);
+        if ((i & 7) == l8) TR[i].y = r;
+    }
+    nn = sqrt(nn);
+    KLHR_WAVE_SYNC();
+    for (int i = l8; i < D; i += 8) TR[i].y = TR[i].y / nn;
+    KLHR_WAVE_SYNC();
+}
+
+// onlinemoments.py:10-18, lane-strided (element-wise: bit-exact)
+__device__ inline void om_update_strided(double *m, double *v, long long N, int D, int l8, const double2 *TR, const double *Z, bool fromZ, double clipb) {
+    const double w = 1.0 / (double)N;
+    for (int i = l8; i < D; i += 8) {
+        double x = fromZ ? clipc(Z[i], clipb) : TR[i].x;
+        double mi = m[i], vi = v[i];
+        double d = x - mi;
+        mi += d * w;
+        vi += -vi * w + d * d * w * (1 - w);
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
+// onlinepca.py:13-26 for one chain.  u (theta - mean) must be in Z; TR[i].y is used as column scratch.
+__device__ inline void pca_update(const KParams &p, long long c, long long n_new, double2 *TR, double *Z, int l8) {
+    const int D = p.D, K = p.J;
+    double *V = p.pca_v + c * (long long)D * K;
+    const long long lim = n_new < K ? n_new : K;
+    for (int col = 0; col < lim; col++) {
+        if (col == n_new - 1) {
+            for (int i = l8; i < D; i += 8) V[i * K + col] = Z[i];
+        } else {
+            const double w = ((double)(n_new - 1) - p.l) / (double)n_new;
+            for (int i = l8; i < D; i += 8) TR[i].y = V[i * K + col];
+            KLHR_WAVE_SYNC();
+            double s = 0, udv = 0;
+            for (int i = 0; i < D; i++) { double vi = TR[i].y; s += vi * vi; }
+            double nv = sqrt(s);
+            for (int i = 0; i < D; i++) udv += Z[i] * TR[i].y;
+            KLHR_WAVE_SYNC();
+            for (int i = l8; i < D; i += 8) TR[i].y = w * TR[i].y + (1 - w) * Z[i] * udv / (nv + p.tol);
+            KLHR_WAVE_SYNC();
+            s = 0; udv = 0;
+            for (int i = 0; i < D; i++) { double vi = TR[i].y; s += vi * vi; }
+            nv = sqrt(s);
+            for (int i = 0; i < D; i++) udv += Z[i] * TR[i].y;
+            KLHR_WAVE_SYNC();
+            for (int i = l8; i < D; i += 8) {
+                double vi = TR[i].y;
+                V[i * K + col] = vi;
+                Z[i] = Z[i] - udv * vi / (nv * nv + p.tol);
+            }
+            KLHR_WAVE_SYNC();
+        }
+    }
+}
+
+// window closure: klhr_sinh.py:268-280 (+ rank permutation for the next windows' direction draws)
+__device__ inline void close_window(const KParams &p, long long c, long long omN, double2 *TR, double *Z, int l8) {
+    const int D = p.D, K = p.J, nc = p.ncol;
+    double *mean = p.mean + c * (long long)D, *cov = p.cov + c * (long long)D;
+    double *om_m = p.om_m + c * (long long)D, *om_v = p.om_v + c * (long long)D;
+    double *V = p.pca_v + c * (long long)D * K;
+    double *evec = p.eigvecs + c * (long long)D * nc, *ev = p.eigvals + c * nc;
+    int *rank = p.rank + c * (long long)D;
+    for (int i = l8; i < D; i += 8) {
+        mean[i] = om_m[i];
+        double cv = omN > 2 ? om_v[i] * (double)omN / (double)(omN - 1) : 1.0;
+        if (p.flags & FLAG_SCALE_DIR_COV) {
+            double *omd_m = p.omd_m + c * (long long)D, *omd_v = p.omd_v + c * (long long)D;
+            double vd = omN > 2 ? omd_v[i] * (double)omN / (double)(omN - 1) : 1.0;
+            cv = cv / (p.tol + vd);
+            omd_m[i] = 0.0; omd_v[i] = 0.0;
+        }
+        cov[i] = cv;
+        Z[i] = cv;
+        om_m[i] = 0.0; om_v[i] = 0.0;
+    }
+    KLHR_WAVE_SYNC();
+    // rank_i = position of i in the stable descending order of cov
+    for (int i = l8; i < D; i += 8) {
+        double ci = Z[i];
+        int r = 0;
+        for (int j = 0; j < D; j++) { double cj = Z[j]; r += (cj > ci || (cj == ci && j < i)) ? 1 : 0; }
+        rank[i] = r;
+    }
+    KLHR_WAVE_SYNC();
+    // OnlinePCA.values()/vectors() (onlinepca.py:28-35)
+    double vals[4] = {0, 0, 0, 0};
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (j < K) {
+            for (int i = l8; i < D; i += 8) TR[i].y = V[i * K + j];
+            KLHR_WAVE_SYNC();
+            double s = 0;
+            for (int i = 0; i < D; i++) { double vi = TR[i].y; s += vi * vi; }
+            vals[j] = sqrt(s);
+            if (!isfinite(vals[j])) bad = true;
+            KLHR_WAVE_SYNC();
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) { if (bad) vals[j] = 0.0; vals[j] += p.tol; }
+    for (int i = l8; i < D; i += 8) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (j < K) { evec[i * nc + j] = V[i * K + j] / vals[j]; V[i * K + j] = 0.0; }
+    }
+    if (l8 == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (j < K) ev[j] = vals[j];
+    }
+    // publish to the other lanes of this wave (they read mean/cov/eigvecs/rank through the vector L1)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+#pragma clang fp contract(fast)
+
+// ------------------------------------------------------------------------------------------------
+template <int MODEL>
+__global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x & 63, grp = lane >> 3, l8 = lane & 7;
+    const long long c = (long long)blockIdx.x * 8 + grp;
+    if (c >= p.C) return;
+    const int D = p.D;
+    double2 *TR = reinterpret_cast<double2 *>(lds + (size_t)grp * p.S);
+    double *Z = lds + (size_t)grp * p.S + 2 * (size_t)D;
+
+    // ---- load chain state
+    double *theta_g = p.theta + c * (long long)D;
+    for (int i = l8; i < D; i += 8) { double2 v; v.x = theta_g[i]; v.y = 0.0; TR[i] = v; }
+    Pcg64 rng;
+    rng.sh = p.rng[c * 4 + 0]; rng.sl = p.rng[c * 4 + 1]; rng.ih = p.rng[c * 4 + 2]; rng.il = p.rng[c * 4 + 3];
+    long long draw = p.counters[c * 4 + 0], omN = p.counters[c * 4 + 1], pcan = p.counters[c * 4 + 2];
+    int cidx = (int)p.counters[c * 4 + 3];
+    double acc = p.acc[c];
+    long long gevals = p.grad_evals[c];
+    const double asx_l = p.asx[l8], w_l = p.wq[l8];
+    KLHR_WAVE_SYNC();
+
+    double eta[4] = {0, 0, 0, 0};
+    double dg_x0 = 0, dg_mode = 0, dg_hinv1 = 0, dg_fun2 = 0, dg_init[4] = {0, 0, 0, 0}, dg_zp = 0, dg_r = 0, dg_logu = 0;
+    int dg_nfev1 = 0, dg_nit1 = 0, dg_st1 = 0, dg_nfev2 = 0, dg_nit2 = 0, dg_st2 = 0, dg_acc = 0, dg_fb = 0, dg_pass = 0;
+
+    for (int iter = 0; iter < p.n_iters; ++iter) {
+        // =============================================================== direction (klhr_sinh.py:264)
+        if (p.phases & PH_DIR) {
+            // eigen_method_one: rng.choice() consumes one uniform BEFORE the D normals (klhr_sinh.py:207,212)
+            const double u_choice = (p.flags & FLAG_EIGEN_ONE) ? pcg_next_double(rng) : 0.0;
+            for (int k = 0; k < D; k++) {
+                double z = rng_std_normal(rng);
+                if ((k & 7) == l8) Z[k] = z;
+            }
+            KLHR_WAVE_SYNC();
+            direction_from_normals(p, c, TR, Z, l8, u_choice);
+        } else {
+            const double *rg = p.d_rho + c * (long long)D;
+            for (int i = l8; i < D; i += 8) TR[i].y = rg[i];
+            KLHR_WAVE_SYNC();
+        }
+        if ((p.flags & FLAG_DIAG) && (p.phases & PH_DIR)) {
+            double *rg = p.d_rho + c * (long long)D;
+            for (int i = l8; i < D; i += 8) rg[i] = TR[i].y;
+        }
+
+        // =============================================================== fit (klhr_sinh.py:182-201)
+        if (p.phases & PH_FIT) {
+            Opt o;
+            {
+                double x0v[4] = {rng_std_normal(rng) * p.initscale, 0, 0, 0};
+                dg_x0 = x0v[0];
+                opt_begin(o, 1, x0v, 1e-5);
+            }
+            bool done = false;
+            dg_pass = 0;
+            for (;;) {
+                double f = 0, g[4] = {0, 0, 0, 0};
+                if (!done) {
+                    if (opt_cache_hit(o)) {
+                        f = o.lf; g[0] = o.lg[0]; g[1] = o.lg[1]; g[2] = o.lg[2]; g[3] = o.lg[3];
+                    } else {
+                        eval_objective<MODEL>(p, TR, o.n, o.xt, asx_l, w_l, f, g);
+                        opt_cache_store(o, f, g);
+                        dg_pass++;
+                    }
+                    opt_advance(o, f, g);
+                    if (o.pc == PC_DONE) {
+                        if (o.n == 1) {
+                            gevals += o.nfev;
+                            dg_mode = o.xk[0]; dg_hinv1 = o.H[0]; dg_nfev1 = o.nfev; dg_nit1 = o.k; dg_st1 = o.status; dg_fb = o.fallbacks;
+                            double s = o.H[0];
+                            s = (s > 0 ? 1.0 : 0.0) * 0.5 * log(s);
+                            double init[4];
+                            for (int k = 0; k < 4; k++) init[k] = rng_std_normal(rng) * p.initscale;
+                            init[0] = o.xk[0];
+                            init[1] = s;
+                            for (int k = 0; k < 4; k++) dg_init[k] = init[k];
+                            opt_begin(o, 4, init, 1e-3);
+                        } else {
+                            gevals += (long long)o.nfev * 8;
+                            for (int k = 0; k < 4; k++) eta[k] = o.xk[k];
+                            dg_nfev2 = o.nfev; dg_nit2 = o.k; dg_st2 = o.status; dg_fun2 = o.old_fval; dg_fb += o.fallbacks;
+                            done = true;
+                        }
+                    }
+                }
+                if (__all(done)) break;
+            }
+            if (p.flags & FLAG_DIAG) {
+                const double e_sel = l8 == 0 ? eta[0] : (l8 == 1 ? eta[1] : (l8 == 2 ? eta[2] : eta[3]));
+                if (l8 < 4) p.d_eta[c * 4 + l8] = e_sel;
+            }
+        } else {
+            for (int k = 0; k < 4; k++) eta[k] = p.d_eta[c * 4 + k];
+        }
+
+        // =============================================================== KL / line probes (API + tests)
+        if (p.phases & (PH_KL | PH_LINE)) {
+            double f, g[4];
+            eval_objective<MODEL>(p, TR, (p.phases & PH_KL) ? 4 : 1, eta, asx_l, w_l, f, g);
+            if (l8 == 0) {
+                double *dd = p.d_diag + c * KLHR_NDIAG;
+                dd[0] = f; dd[1] = g[0]; dd[2] = g[1]; dd[3] = g[2]; dd[4] = g[3];
+            }
+        }
+
+        // =============================================================== MH step (klhr_sinh.py:242-260)
+        if (p.phases & PH_MH) {
+            draw += 1;
+            const double z = rng_std_normal(rng);
+            const double zp = sa_T(z, eta, p.tol, p.scale_clip);
+            double logp, gdot;
+            const double t = (l8 == 0) ? zp : 0.0;
+            model_eval<MODEL>(p.md, [&](int i, double &xi, double &ri) { double2 v = TR[i]; ri = v.y; xi = fma(t, v.y, v.x); },
+                              INFINITY, NoSink(), logp, gdot);
+            const double lp_p = __shfl(logp, (grp << 3) + 0);
+            const double lp_c = __shfl(logp, (grp << 3) + 1);
+            double r = lp_p;
+            r -= lp_c;
+            r += sa_log_q(0.0, eta, p.tol, p.scale_clip);
+            r -= sa_log_q(zp, eta, p.tol, p.scale_clip);
+            const double logu = log(rng_uniform(rng));
+            const double mn = (r != r) ? r : (r < 0 ? r : 0.0);      // np.minimum(0, r)
+            const int a = logu < mn ? 1 : 0;
+            const double ad = (double)a, na = (double)(1 - a);
+            for (int i = l8; i < D; i += 8) {
+                double2 v = TR[i];
+                double thp = __dadd_rn(__dmul_rn(zp, v.y), v.x);
+                v.x = __dadd_rn(__dmul_rn(ad, thp), __dmul_rn(na, v.x));     // a*thetap + (1-a)*theta
+                TR[i] = v;
+            }
+            acc += (ad - acc) / (double)draw;
+            dg_zp = zp; dg_r = r; dg_logu = logu; dg_acc = a;
+            KLHR_WAVE_SYNC();
+        }
+
+        // =============================================================== closure-or-update (klhr_sinh.py:268-287)
+        if (p.phases & PH_ADAPT) {
+            bool closed = false;
+            if (!(p.warmup < p.windowsize) && p.nclos > 0) {
+                closed = draw == p.closures[cidx];
+                if (closed && cidx < p.nclos - 1) cidx++;
+            }
+            if (closed) {
+                close_window(p, c, omN, TR, Z, l8);
+                omN = 0;
+                pcan = 0;
+            } else {
+                omN += 1;
+                if (p.flags & FLAG_SCALE_DIR_COV) {
+                    // _logp_grad(theta): gradient clipped at +-scale_clip feeds the density moments
+                    double lp_, gd_;
+                    model_eval<MODEL>(p.md, [&](int i, double &xi, double &ri) { double2 v = TR[i]; xi = v.x; ri = 0.0; }, INFINITY,
+                                      [&](int i, double gi) { if ((i & 7) == l8) Z[i] = gi; }, lp_, gd_);
+                    KLHR_WAVE_SYNC();
+                    om_update_strided(p.omd_m + c * (long long)D, p.omd_v + c * (long long)D, omN, D, l8, TR, Z, true, p.scale_clip);
+                    KLHR_WAVE_SYNC();
+                }
+                om_update_strided(p.om_m + c * (long long)D, p.om_v + c * (long long)D, omN, D, l8, TR, Z, false, 0.0);
+                const double *mean = p.mean + c * (long long)D;
+                for (int i = l8; i < D; i += 8) Z[i] = __dsub_rn(TR[i].x, mean[i]);
+                KLHR_WAVE_SYNC();
+                pcan += 1;
+                pca_update(p, c, pcan, TR, Z, l8);
+            }
+        }
+
+        // =============================================================== outputs of this iteration
+        if (p.draws) {
+            double *out = p.draws + ((long long)iter * p.C + c) * D;
+            for (int i = l8; i < D; i += 8) out[i] = TR[i].x;
+        }
+    }
+
+    // ---- store chain state
+    bool finite_theta = true;
+    for (int i = l8; i < D; i += 8) { double v = TR[i].x; theta_g[i] = v; if (!isfinite(v)) finite_theta = false; }
+    {
+        unsigned long long b = __ballot(!finite_theta);
+        if (((b >> (grp << 3)) & 0xffULL) && l8 == 0) atomicOr(&p.status[c], 2);
+    }
+    if (l8 == 0) {
+        p.rng[c * 4 + 0] = rng.sh; p.rng[c * 4 + 1] = rng.sl; p.rng[c * 4 + 2] = rng.ih; p.rng[c * 4 + 3] = rng.il;
+        p.counters[c * 4 + 0] = draw; p.counters[c * 4 + 1] = omN; p.counters[c * 4 + 2] = pcan; p.counters[c * 4 + 3] = cidx;
+        p.acc[c] = acc;
+        p.grad_evals[c] = gevals;
+        if ((p.flags & FLAG_DIAG) && !(p.phases & (PH_KL | PH_LINE))) {
+            double *dd = p.d_diag + c * KLHR_NDIAG;
+            dd[KLHR_D_X0] = dg_x0; dd[KLHR_D_MODE] = dg_mode; dd[KLHR_D_HINV1] = dg_hinv1; dd[KLHR_D_NFEV1] = dg_nfev1;
+            dd[KLHR_D_NIT1] = dg_nit1; dd[KLHR_D_STATUS1] = dg_st1; dd[KLHR_D_INIT0] = dg_init[0]; dd[KLHR_D_INIT1] = dg_init[1];
+            dd[KLHR_D_INIT2] = dg_init[2]; dd[KLHR_D_INIT3] = dg_init[3]; dd[KLHR_D_NFEV2] = dg_nfev2; dd[KLHR_D_NIT2] = dg_nit2;
+            dd[KLHR_D_STATUS2] = dg_st2; dd[KLHR_D_FUN2] = dg_fun2; dd[KLHR_D_ZP] = dg_zp; dd[KLHR_D_R] = dg_r;
+            dd[KLHR_D_LOGU] = dg_logu; dd[KLHR_D_ACCEPT] = dg_acc; dd[KLHR_D_FALLBACKS] = dg_fb; dd[KLHR_D_PASSES] = dg_pass;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MCMCBase.__init__ (mcmc.py:15) + KLHRSINH._initialize (klhr_sinh.py:86-98), one thread per chain.
+template <int MODEL>
+__global__ void klhr_init_kernel(const KParams p, int theta_given, int max_tries) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= p.C) return;
+    const int D = p.D;
+    Pcg64 rng;
+    rng.sh = p.rng[c * 4 + 0]; rng.sl = p.rng[c * 4 + 1]; rng.ih = p.rng[c * 4 + 2]; rng.il = p.rng[c * 4 + 3];
+    double *th = p.theta + c * (long long)D;
+    if (!theta_given)
+        for (int i = 0; i < D; i++) (void)rng_std_normal(rng);     // rng.normal(scale=0.1, size=D), overwritten below
+    int tries = 0, st = 0;
+    for (;;) {
+        tries++;
+        for (int i = 0; i < D; i++) th[i] = rng_std_normal(rng) * p.initscale;
+        double lp, gd, n2 = 0;
+        model_eval<MODEL>(p.md, [&](int i, double &xi, double &ri) { xi = th[i]; ri = 0.0; }, INFINITY,
+                          [&](int, double gi) { n2 += gi * gi; }, lp, gd);
+        if (isfinite(lp) && isfinite(sqrt(n2))) break;
+        if (tries >= max_tries) { st = 1; break; }
+    }
+    p.rng[c * 4 + 0] = rng.sh; p.rng[c * 4 + 1] = rng.sl; p.rng[c * 4 + 2] = rng.ih; p.rng[c * 4 + 3] = rng.il;
+    p.status[c] = st;
+}
+
+// BSModel.log_density / log_density_gradient (bsmodel.py:15-30) for n points, one thread per point.
+template <int MODEL>
+__global__ void klhr_logp_kernel(ModelData md, const double *thetas, long long n, double *lp_out, double *grad_out) {
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const double *th = thetas + k * md.D;
+    double lp, gd;
+    if (grad_out) {
+        double *go = grad_out + k * md.D;
+        model_eval<MODEL>(md, [&](int i, double &xi, double &ri) { xi = th[i]; ri = 0.0; }, INFINITY,
+                          [&](int i, double gi) { go[i] = gi; }, lp, gd);
+    } else {
+        model_eval<MODEL>(md, [&](int i, double &xi, double &ri) { xi = th[i]; ri = 0.0; }, INFINITY, NoSink(), lp, gd);
+    }
+    lp_out[k] = lp;
+}
+
+// sinh-arcsinh primitives for n (x, eta) pairs (klhr_sinh.py:112-156,230-240)
+__global__ void klhr_prim_kernel(const double *x, const double *eta, long long n, double tol, double sc, double *out) {
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const double *e4 = eta + k * 4;
+    const double xv = x[k];
+    double m, s, d, e;
+    sa_unpack(e4, tol, sc, m, s, d, e);
+    double *o = out + k * 12;
+    o[0] = sa_T(xv, e4, tol, sc);
+    o[1] = sa_T_inv(xv, e4, tol, sc);
+    const double a_div = (asinh(xv) + e) / d;
+    o[2] = (e4[2] - e4[1]) - log(cosh(clipc(a_div, sc)));
+    o[3] = sa_log_q(xv, e4, tol, sc);
+    const double invd = 1 / d, a = (asinh(xv) + e) * invd, ac = clipc(a, sc);
+    o[4] = 1.0; o[5] = s * sinh(ac); o[6] = -s * cosh(ac) * a; o[7] = s * cosh(ac) * invd;
+    const double t = tanh(ac);
+    o[8] = 0.0; o[9] = -1.0; o[10] = 1 + t * a; o[11] = -t * invd;
+}
+
+// MH.draw() (mh.py:18-37), one thread per chain; proposal scratch in p.d_rho (C×D)
+template <int MODEL>
+__global__ void klhr_mh_kernel(const KParams p, double stepsize, int seed_only) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= p.C) return;
+    const int D = p.D;
+    Pcg64 rng;
+    rng.sh = p.rng[c * 4 + 0]; rng.sl = p.rng[c * 4 + 1]; rng.ih = p.rng[c * 4 + 2]; rng.il = p.rng[c * 4 + 3];
+    double *th = p.theta + c * (long long)D;
+    double *pr = p.d_rho + c * (long long)D;
+    long long draw = p.counters[c * 4 + 0];
+    double acc = p.acc[c];
+    if (seed_only) {
+        for (int i = 0; i < D; i++) th[i] = 0.0 + 0.1 * rng_std_normal(rng);     // mcmc.py:15
+        draw = 0; acc = 0;
+    }
+    for (int it = 0; it < (seed_only ? 0 : p.n_iters); ++it) {
+        draw += 1;
+        for (int i = 0; i < D; i++) pr[i] = rng_std_normal(rng);
+        for (int i = 0; i < D; i++) pr[i] = __dadd_rn(th[i], __dmul_rn(pr[i], stepsize));
+        double lpp, lpc, gd;
+        model_eval<MODEL>(p.md, [&](int i, double &xi, double &ri) { xi = pr[i]; ri = 0.0; }, INFINITY, NoSink(), lpp, gd);
+        model_eval<MODEL>(p.md, [&](int i, double &xi, double &ri) { xi = th[i]; ri = 0.0; }, INFINITY, NoSink(), lpc, gd);
+        double r = lpp;
+        r -= lpc;
+        double q1 = 0, q2 = 0;
+        for (int i = 0; i < D; i++) { double z = (th[i] - pr[i]) / stepsize; q1 += z * z; }
+        for (int i = 0; i < D; i++) { double z = (pr[i] - th[i]) / stepsize; q2 += z * z; }
+        r += -0.5 * q1;
+        r -= -0.5 * q2;
+        const double logu = log(rng_uniform(rng));
+        const double mn = (r != r) ? r : (r < 0 ? r : 0.0);
+        const int a = logu < mn ? 1 : 0;
+        const double ad = (double)a, na = (double)(1 - a);
+        for (int i = 0; i < D; i++) th[i] = __dadd_rn(__dmul_rn(ad, pr[i]), __dmul_rn(na, th[i]));
+        acc += (ad - acc) / (double)draw;
+        if (p.draws) {
+            double *out = p.draws + ((long long)it * p.C + c) * D;
+            for (int i = 0; i < D; i++) out[i] = th[i];
+        }
+    }
+    p.rng[c * 4 + 0] = rng.sh; p.rng[c * 4 + 1] = rng.sl; p.rng[c * 4 + 2] = rng.ih; p.rng[c * 4 + 3] = rng.il;
+    p.counters[c * 4 + 0] = draw;
+    p.acc[c] = acc;
+}
+
+// rank permutation of cov after klhr_set_state(KLHR_F_COV)
+__global__ void klhr_rank_kernel(const double *cov, int *rank, int C, int D) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double *cv = cov + c * (long long)D;
+    int *rk = rank + c * (long long)D;
+    for (int i = 0; i < D; i++) {
+        int r = 0;
+        for (int j = 0; j < D; j++) r += (cv[j] > cv[i] || (cv[j] == cv[i] && j < i)) ? 1 : 0;
+        rk[i] = r;
+    }
+}
+
+// pooled-adaptation sufficient statistics over this GPU's chains: out = [n, sum m_i (D), sum (v_i + m_i^2) (D)]
+__global__ void klhr_pool_kernel(const double *om_m, const double *om_v, const long long *counters, int C, int D, double *out) {
+    const int i = blockIdx.x;        // coordinate
+    double sm = 0, sq = 0, sn = 0;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double n = (double)counters[c * 4 + 1];
+        double m = om_m[(long long)c * D + i], v = om_v[(long long)c * D + i];
+        sm += n * m;
+        sq += n * (v + m * m);
+        sn += n;
+    }
+    __shared__ double red[3][256];
+    red[0][threadIdx.x] = sm; red[1][threadIdx.x] = sq; red[2][threadIdx.x] = sn;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) { red[0][threadIdx.x] += red[0][threadIdx.x + s]; red[1][threadIdx.x] += red[1][threadIdx.x + s]; red[2][threadIdx.x] += red[2][threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[1 + i] = red[0][0]; out[1 + D + i] = red[1][0]; if (i == 0) out[0] = red[2][0]; }
+}
+
+__global__ void klhr_pool_apply_kernel(const double *mean_in, const double *cov_in, double *mean, double *cov, int *rank, int C, int D) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    for (int i = 0; i < D; i++) { mean[c * (long long)D + i] = mean_in[i]; cov[c * (long long)D + i] = cov_in[i]; }
+    for (int i = 0; i < D; i++) {
+        int r = 0;
+        for (int j = 0; j < D; j++) r += (cov_in[j] > cov_in[i] || (cov_in[j] == cov_in[i] && j < i)) ? 1 : 0;
+        rank[c * (long long)D + i] = r;
+    }
+}
+
+}  // namespace klhr
