@@ -19,7 +19,9 @@
 // Problems of dimension n=1 (mode search) run through the same 4-wide code with zero padding: padded
 // coordinates have zero gradient, so H stays block-diagonal and every padded term adds an exact 0.
 #pragma once
+#ifndef KLHR_HOST_HARNESS
 #include <hip/hip_runtime.h>
+#endif
 #include <math.h>
 
 namespace klhr {
