@@ -1,0 +1,166 @@
+"""GPU tests of the Python host layer that mirrors the reference's classes (klhr_amd/{bsmodel,klhr_sinh,mh,mcmc}.py):
+a user of the reference's API gets the reference's numbers."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden
+
+pytestmark = pytest.mark.gpu
+STAN = os.path.join(ROOT, "klhr_amd", "stan")
+
+
+def funnel_model():
+    from klhr_amd import BSModel
+    return BSModel(os.path.join(STAN, "funnel.stan"), os.path.join(STAN, "funnel.json"))
+
+
+def test_bsmodel_surface_on_device():
+    g = golden("g4_kl.npz")
+    m = funnel_model()
+    th = g["funnel10_theta"]
+    for i in (0, 3, 9):
+        lp, grad = m.log_density_gradient(th[i])
+        assert isinstance(lp, float) and grad.shape == (10,)
+        assert abs(lp - g["funnel10_lp"][i]) <= 1e-12 * abs(g["funnel10_lp"][i])
+        assert np.allclose(grad, g["funnel10_lpgrad"][i], rtol=1e-12)
+        assert m.log_density(th[i]) == lp
+    lp_all = m.log_density(th)
+    assert lp_all.shape == (th.shape[0],)
+    lp, H = m.log_density_hessian(th[0])
+    assert H.shape == (10, 10) and np.allclose(H, H.T)
+    ev = np.exp(-th[0][0])
+    assert np.allclose(np.diag(H)[1:], -ev, rtol=1e-5)           # d2/dalpha2 = -exp(-v)
+    assert m.Hamiltonian(th[0], np.ones(10)) == pytest.approx(-lp + 5.0)
+    # error convention of bsmodel.py:15-30: failure -> -inf and zero gradient
+    bad = th[0].copy()
+    bad[0] = np.nan
+    lp, grad = m.log_density_gradient(bad)
+    assert lp == -np.inf and not grad.any()
+
+
+def test_klhrsinh_single_chain_is_the_reference_chain():
+    from klhr_amd import KLHRSINH
+    g = golden("g8_public_api.npz")
+    g0 = golden("g8_funnel10_s0_w100.npz")
+    algo = KLHRSINH(funnel_model(), seed=0, warmup=100, overrelaxed=False)
+    assert algo.D == 10 and algo.theta.shape == (10,)
+    assert np.array_equal(algo.theta, g0["theta0"])
+    st = algo.rng.bit_generator.state["state"]
+    assert (st["state"] >> 64, st["state"] & (2**64 - 1)) == (int(g0["state_before"][0][0]), int(g0["state_before"][0][1]))
+    th = np.array([algo.draw() for _ in range(40)])
+    assert th.shape == (40, 10)
+    assert np.abs(th - g["s0_thetas"][:40]).max() < 1e-9
+    assert algo.acceptance_probability.shape == (1,)
+    assert algo.acceptance_probability[0] == pytest.approx(g0["accprob"][39], abs=1e-12)
+    assert algo.grad_evals == g0["grad_evals"][39]
+    more = np.array([next(algo) for _ in range(3)])          # iterator protocol (mcmc.py:19-23)
+    assert np.abs(more - g["s0_thetas"][40:43]).max() < 1e-9
+
+
+def test_sample_row0_is_initial_point():
+    from klhr_amd import BSModel, KLHRSINH
+    g = golden("g8_public_api.npz")
+    m = BSModel(os.path.join(STAN, "normal.stan"), os.path.join(STAN, "normal.json"))
+    algo = KLHRSINH(m, seed=3, warmup=100, overrelaxed=False)
+    init = algo.theta.copy()
+    s = algo.sample(50)
+    assert s.shape == (50, 2) and np.array_equal(s[0], init)
+    assert np.abs(s - g["sample_normal2"]).max() < 1e-9
+
+
+def test_many_chains_each_is_a_reference_chain():
+    from klhr_amd import KLHRSINH
+    algo = KLHRSINH(funnel_model(), seed=0, warmup=100, overrelaxed=False, chains=4)     # chain c <- default_rng(0 + c)
+    dr = algo.draws(50)
+    assert dr.shape == (50, 4, 10)
+    for c in range(4):
+        g = golden(f"g8_funnel10_s{c}_w100.npz")
+        assert np.abs(dr[:, c] - g["theta_after"][:50]).max() < 1e-9, c
+    assert algo.acceptance_probability.shape == (4,) and algo.grad_evals.shape == (4,)
+
+
+def test_pieces_with_reference_method_names(oracle):
+    from klhr_amd import KLHRSINH
+    g = golden("g8_funnel10_s1_w100.npz")
+    algo = KLHRSINH(funnel_model(), seed=1, warmup=100, overrelaxed=False)
+    rho = algo._random_direction()
+    assert np.array_equal(rho, g["rho"][0])
+    eta = algo.fit(rho)
+    assert np.allclose(eta, g["eta"][0], rtol=1e-6, atol=1e-8)
+    v, grad = algo.KL(eta, rho)
+    assert np.max(np.abs(grad)) < 1e-3          # BFGS stopped at gtol = 1e-3 (klhr_sinh.py:199)
+    f, df = algo.logp_grad_rho(g["mode"][0], rho)
+    assert abs(df) < 1e-5
+    th = algo._metropolis_step(g["eta"][0], rho)
+    assert np.allclose(th, g["theta_after"][0], rtol=1e-10, atol=1e-12)
+    assert algo._log_q(0.3, eta) == pytest.approx(float(oracle.Chain("funnel", {"D": 9}).primitives_inv(0.3, eta)["log_q"]), rel=1e-12)
+    assert algo._grad_T(0.0, eta).shape == (4,)
+
+
+def test_overrelaxed_default_fails_loudly():
+    from klhr_amd import KLHRSINH
+    with pytest.raises(NotImplementedError):
+        KLHRSINH(funnel_model(), seed=0)
+
+
+def test_mh_class_vs_golden():
+    from klhr_amd import BSModel, MH
+    g = golden("g9_mh.npz")
+    m = BSModel(os.path.join(STAN, "normal.stan"), os.path.join(STAN, "normal.json"))
+    mh = MH(m, 0.09, seed=0)
+    assert np.array_equal(mh.theta, g["normal2_s0_theta0"])
+    th = np.array([mh.draw() for _ in range(30)])
+    assert np.allclose(th, g["normal2_s0_thetas"][:30], atol=1e-12)
+    rest = mh.draws(1970)
+    assert np.allclose(rest[-1], g["normal2_s0_last"], atol=1e-12)
+    assert mh.acceptance_probability[0] == pytest.approx(g["normal2_s0_acc"][0], abs=1e-12)
+
+
+def test_experiment_harnesses_run(tmp_path):
+    from click.testing import CliRunner
+    from klhr_amd.experiment_accuracy import main as acc_main
+    from klhr_amd.experiment_funnel import main as funnel_main
+    r = CliRunner().invoke(funnel_main, ["-M", "150", "-w", "100", "--chains", "8", "--seed", "1", "--outdir", str(tmp_path), "-v", "klhr_sinh"])
+    assert r.exit_code == 0, r.output
+    assert "Acceptance rate" in r.output and os.path.exists(tmp_path / "histogram_False_False_False_klhr_sinh.png")
+    r = CliRunner().invoke(acc_main, ["-M", "300", "--seed", "2", "--outdir", str(tmp_path), "-v", "klhr_sinh"])
+    assert r.exit_code == 0, r.output
+    assert "final RMSE" in r.output
+
+
+def test_statistical_targets_funnel_and_normal():
+    """The reference's own (eyeballed) integration checks as numbers: v ~ N(0, 3) on the funnel
+    (experiment_funnel.py:66-72) and unit variances on stan/normal (experiment_accuracy.py:97)."""
+    from klhr_amd import BSModel, KLHRSINH
+    algo = KLHRSINH(funnel_model(), seed=11, warmup=100, overrelaxed=False, chains=2048)
+    dr = algo.draws(400)[100:]
+    v = dr[:, :, 0].reshape(-1)
+    assert abs(v.mean()) < 0.25 and 2.5 < v.std() < 3.5, (v.mean(), v.std())
+    m = BSModel(os.path.join(STAN, "normal.stan"), os.path.join(STAN, "normal-100.json"))
+    algo = KLHRSINH(m, seed=5, warmup=100, overrelaxed=False, chains=256)
+    dr = algo.draws(600)[200:].reshape(-1, 100)
+    assert np.abs(dr.mean(axis=0)).max() < 0.1 and np.abs(dr.var(axis=0) - 1).max() < 0.15
+
+
+def test_pooled_adaptation_single_rank():
+    from klhr_amd.parallel import ShardedKLHRSINH
+    sh = ShardedKLHRSINH(funnel_model(), 64, seed=3, pooled=True, warmup=100)
+    sh.advance(49)
+    s = sh.local._sampler
+    st = s.pool_stats()
+    assert st[0] == 64 * 49
+    om_m = s.get("om_m")
+    assert np.allclose(st[1:11], 49 * om_m.sum(axis=0), rtol=1e-12)
+    sh.advance(2)                       # crosses the closure at draw 50
+    mean, cov = s.get("mean"), s.get("cov")
+    assert np.all(mean == mean[0]) and np.all(cov == cov[0])         # every chain carries the pooled values
+    assert np.allclose(mean[0], st[1:11] / st[0], rtol=1e-12)
+    sh.advance(60)                      # and keeps sampling through the second closure
+    assert np.isfinite(s.get("theta")).all()
+    # parity mode leaves per-chain adaptation untouched
+    sp = ShardedKLHRSINH(funnel_model(), 64, seed=3, pooled=False, warmup=100)
+    sp.advance(51)
+    m2 = sp.local._sampler.get("mean")
+    assert not np.all(m2 == m2[0])
