@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libklhr_hip.so")
+LIB_PATH = os.environ.get("KLHR_LIB") or os.path.join(HERE, "lib", "libklhr_hip.so")   # KLHR_LIB: diagnostic builds
 
 NDIAG = 20
 DIAG_COLS = ["x0", "mode", "hinv1", "nfev1", "nit1", "status1", "init0", "init1", "init2", "init3", "nfev2", "nit2",

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libklhr_hip.so")
 SOURCES = ["klhr_api.hip"]
-DEPS = ["klhr_api.hip", "klhr_kernels.hpp", "device_opt.hpp", "device_models.hpp", "device_rng.hpp", "zig_tables.h",
+DEPS = ["klhr_api.hip", "klhr_kernels.hpp", "klhr_lane_kernel.hpp", "device_opt.hpp", "device_models.hpp", "device_rng.hpp", "zig_tables.h",
         os.path.join("..", "..", "include", "klhr.h")]
 
 

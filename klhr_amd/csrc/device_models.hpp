@@ -118,3 +118,100 @@ __device__ __forceinline__ void model_eval(const ModelData &md, XR xr, double cl
 }
 
 }  // namespace klhr
+
+// ---------------------------------------------------------------------------------------------------------------
+// NV-way evaluator for the lane-per-chain kernel: ONE pass over a chain's (theta_i, rho_i) pairs evaluates the log
+// density and clip(grad).rho at NV points theta + t[n]*rho simultaneously.  The NV accumulator chains are independent
+// (instruction-level parallelism for a wavefront that is alone on its SIMD) and each LDS read is reused NV times.
+// Per point the arithmetic and its order are exactly those of model_eval above.
+namespace klhr {
+
+template <int MODEL, int NV>
+__device__ __forceinline__ void model_eval_nv(const ModelData &md, const double2 *TR, const double (&t)[NV], double cl,
+                                              double (&logp)[NV], double (&gdot)[NV]) {
+    const int D = md.D;
+    if constexpr (MODEL == MODEL_FUNNEL) {
+        const double2 e0 = TR[0];
+        const double Da = (double)md.n;
+        double v[NV], ev[NV], ss[NV], gd[NV];
+#pragma unroll
+        for (int n = 0; n < NV; n++) { v[n] = fma(t[n], e0.y, e0.x); ev[n] = exp(-v[n]); ss[n] = 0.0; gd[n] = 0.0; }
+        for (int i = 1; i < D; i++) {
+            const double2 e = TR[i];
+#pragma unroll
+            for (int n = 0; n < NV; n++) {
+                double xi = fma(t[n], e.y, e.x);
+                ss[n] += xi * xi;
+                double gi = -ev[n] * xi;
+                gd[n] += clipc(gi, cl) * e.y;
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NV; n++) {
+            double g0 = -v[n] / 9.0 - 0.5 * Da + 0.5 * ev[n] * ss[n];
+            gdot[n] = clipc(g0, cl) * e0.y + gd[n];
+            logp[n] = -v[n] * v[n] / 18.0 - 0.5 * Da * v[n] - 0.5 * ev[n] * ss[n];
+        }
+    } else if constexpr (MODEL == MODEL_ILL_NORMAL || MODEL == MODEL_NORMAL) {
+        double acc[NV], gd[NV];
+#pragma unroll
+        for (int n = 0; n < NV; n++) { acc[n] = 0.0; gd[n] = 0.0; }
+        for (int i = 0; i < D; i++) {
+            const double2 e = TR[i];
+            const double is = (MODEL == MODEL_ILL_NORMAL) ? md.aux[i] : 1.0;
+#pragma unroll
+            for (int n = 0; n < NV; n++) {
+                double xi = fma(t[n], e.y, e.x);
+                double gi;
+                if constexpr (MODEL == MODEL_ILL_NORMAL) { double z = xi * is; acc[n] += z * z; gi = -z * is; }
+                else { acc[n] += xi * xi; gi = -xi; }
+                gd[n] += clipc(gi, cl) * e.y;
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NV; n++) { gdot[n] = gd[n]; logp[n] = -0.5 * acc[n]; }
+    } else {   // MODEL_GLMM_POISSON
+        const int nn = md.n;
+        const double *x1 = md.aux, *x2 = md.aux + nn, *x3 = md.aux + 2 * nn, *Cn = md.aux + 3 * nn;
+        const double2 ea = TR[0], eb0 = TR[1], eb1 = TR[2], eb2 = TR[3], el = TR[4];
+        double alpha[NV], b0[NV], b1[NV], b2[NV], ell[NV], sigma[NV], sr[NV], s1[NV], s2[NV], s3[NV], sre[NV], see[NV], lik[NV], gd[NV];
+#pragma unroll
+        for (int n = 0; n < NV; n++) {
+            alpha[n] = fma(t[n], ea.y, ea.x); b0[n] = fma(t[n], eb0.y, eb0.x); b1[n] = fma(t[n], eb1.y, eb1.x);
+            b2[n] = fma(t[n], eb2.y, eb2.x); ell[n] = fma(t[n], el.y, el.x); sigma[n] = exp(ell[n]);
+            sr[n] = s1[n] = s2[n] = s3[n] = sre[n] = see[n] = lik[n] = gd[n] = 0.0;
+        }
+        for (int i = 0; i < nn; i++) {
+            const double2 e2 = TR[5 + i];
+#pragma unroll
+            for (int n = 0; n < NV; n++) {
+                double e = fma(t[n], e2.y, e2.x);
+                double eta = alpha[n] + x1[i] * b0[n] + x2[i] * b1[n] + x3[i] * b2[n] + sigma[n] * e;
+                double mu = exp(eta);
+                double r = Cn[i] - mu;
+                lik[n] += Cn[i] * eta - mu;
+                see[n] += e * e;
+                sr[n] += r; s1[n] += x1[i] * r; s2[n] += x2[i] * r; s3[n] += x3[i] * r;
+                sre[n] += r * e;
+                double ge = -e + sigma[n] * r;
+                gd[n] += clipc(ge, cl) * e2.y;
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NV; n++) {
+            double lp = -alpha[n] * alpha[n] / 50.0;
+            lp -= b0[n] * b0[n] / 50.0; lp -= b1[n] * b1[n] / 50.0; lp -= b2[n] * b2[n] / 50.0;
+            lp -= 0.5 * ell[n] * ell[n];
+            lp += -0.5 * see[n] + lik[n];
+            double g0 = -alpha[n] / 25.0 + sr[n], g1 = -b0[n] / 25.0 + s1[n], g2 = -b1[n] / 25.0 + s2[n], g3 = -b2[n] / 25.0 + s3[n];
+            double g4 = -ell[n] + sigma[n] * sre[n];
+            double g = gd[n];
+            g += clipc(g0, cl) * ea.y; g += clipc(g1, cl) * eb0.y; g += clipc(g2, cl) * eb1.y; g += clipc(g3, cl) * eb2.y;
+            g += clipc(g4, cl) * el.y;
+            gdot[n] = g;
+            logp[n] = lp;
+        }
+    }
+}
+
+}  // namespace klhr

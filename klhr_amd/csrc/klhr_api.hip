@@ -7,11 +7,13 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "klhr_kernels.hpp"
+#include "klhr_lane_kernel.hpp"
 
 using namespace klhr;
 
@@ -19,7 +21,8 @@ static thread_local std::string g_create_err;
 
 struct klhr_sampler {
     klhr_config cfg{};
-    int C = 0, D = 0, ncol = 0, S = 0, n_model = 0;
+    int C = 0, D = 0, ncol = 0, S = 0, S_lane = 0, n_model = 0;
+    bool use_lane = false;       // lane-per-chain kernel (small D) instead of the octet-per-chain kernel
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing_pending = false;
@@ -197,6 +200,15 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
     int S = 3 * D;
     while (S % 32 != 4) S++;
     s->S = S;
+    // lane-per-chain kernel: 64 chains per wavefront, stride ≡ 2 (mod 32) doubles; used while it fits 64 KB of LDS
+    int SL = 3 * D;
+    while (SL % 32 != 2) SL++;
+    s->S_lane = SL;
+    s->use_lane = (D <= 26) && ((size_t)64 * SL * 8 <= 64 * 1024);
+    if (const char *kk = getenv("KLHR_KERNEL")) {
+        if (!strcmp(kk, "octet")) s->use_lane = false;
+        else if (!strcmp(kk, "lane") && (size_t)64 * SL * 8 <= 64 * 1024) s->use_lane = true;
+    }
     auto bail = [&](int rc) { g_create_err = s->err; klhr_destroy(s); return rc; };
     {
         hipError_t e = hipSetDevice(cfg->device);
@@ -254,14 +266,28 @@ extern "C" int klhr_sync(klhr_sampler *s) {
 }
 
 // ---- launches ------------------------------------------------------------------------------------
-static int launch_iter(klhr_sampler *s, const KParams &kp) {
-    const dim3 grid((kp.C + 7) / 8), block(64);
-    const size_t lds = (size_t)8 * kp.S * sizeof(double);
-    switch (s->cfg.model_id) {
-    case KLHR_MODEL_FUNNEL: hipLaunchKernelGGL(klhr_iter_kernel<MODEL_FUNNEL>, grid, block, lds, s->stream, kp); break;
-    case KLHR_MODEL_ILL_NORMAL: hipLaunchKernelGGL(klhr_iter_kernel<MODEL_ILL_NORMAL>, grid, block, lds, s->stream, kp); break;
-    case KLHR_MODEL_GLMM_POISSON: hipLaunchKernelGGL(klhr_iter_kernel<MODEL_GLMM_POISSON>, grid, block, lds, s->stream, kp); break;
-    default: hipLaunchKernelGGL(klhr_iter_kernel<MODEL_NORMAL>, grid, block, lds, s->stream, kp); break;
+static int launch_iter(klhr_sampler *s, const KParams &kp_in) {
+    KParams kp = kp_in;
+    if (s->use_lane) {
+        kp.S = s->S_lane;
+        const dim3 grid((kp.C + 63) / 64), block(64);
+        const size_t lds = (size_t)64 * kp.S * sizeof(double);
+        switch (s->cfg.model_id) {
+        case KLHR_MODEL_FUNNEL: hipLaunchKernelGGL(klhr_lane_kernel<MODEL_FUNNEL>, grid, block, lds, s->stream, kp); break;
+        case KLHR_MODEL_ILL_NORMAL: hipLaunchKernelGGL(klhr_lane_kernel<MODEL_ILL_NORMAL>, grid, block, lds, s->stream, kp); break;
+        case KLHR_MODEL_GLMM_POISSON: hipLaunchKernelGGL(klhr_lane_kernel<MODEL_GLMM_POISSON>, grid, block, lds, s->stream, kp); break;
+        default: hipLaunchKernelGGL(klhr_lane_kernel<MODEL_NORMAL>, grid, block, lds, s->stream, kp); break;
+        }
+    } else {
+        kp.S = s->S;
+        const dim3 grid((kp.C + 7) / 8), block(64);
+        const size_t lds = (size_t)8 * kp.S * sizeof(double);
+        switch (s->cfg.model_id) {
+        case KLHR_MODEL_FUNNEL: hipLaunchKernelGGL(klhr_iter_kernel<MODEL_FUNNEL>, grid, block, lds, s->stream, kp); break;
+        case KLHR_MODEL_ILL_NORMAL: hipLaunchKernelGGL(klhr_iter_kernel<MODEL_ILL_NORMAL>, grid, block, lds, s->stream, kp); break;
+        case KLHR_MODEL_GLMM_POISSON: hipLaunchKernelGGL(klhr_iter_kernel<MODEL_GLMM_POISSON>, grid, block, lds, s->stream, kp); break;
+        default: hipLaunchKernelGGL(klhr_iter_kernel<MODEL_NORMAL>, grid, block, lds, s->stream, kp); break;
+        }
     }
     HIPCHECK(s, hipGetLastError());
     return 0;
@@ -282,7 +308,7 @@ static int run_phases(klhr_sampler *s, int phases, int64_t n_iters, int record_d
     HIPCHECK(s, hipSetDevice(s->cfg.device));
     if (record_draws) { int rc = ensure_draws(s, n_iters); if (rc) return rc; s->draws_iters = n_iters; }
     // chunk the iterations so that a single launch stays short; chain state persists in HBM between launches
-    const int64_t chunk_max = 64;
+    const int64_t chunk_max = 50;
     HIPCHECK(s, hipEventRecord(s->ev0, s->stream));
     int launches = 0;
     for (int64_t done = 0; done < n_iters; done += chunk_max) {

@@ -23,6 +23,14 @@
 #include "device_rng.hpp"
 #include "../../include/klhr.h"
 
+// Diagnostic build only (-DKLHR_STAMPS): per-wave cycle totals of each phase, written to d_diag[c][0..7] instead of
+// the usual diagnostics.  The production library never contains a stamp.
+#ifdef KLHR_STAMPS
+#define KLHR_STAMP(acc) do { unsigned long long _t = __builtin_readcyclecounter(); (acc) += _t - stamp_t; stamp_t = _t; } while (0)
+#else
+#define KLHR_STAMP(acc) do { } while (0)
+#endif
+
 namespace klhr {
 
 enum { PH_DIR = 1, PH_FIT = 2, PH_MH = 4, PH_ADAPT = 8, PH_ALL = 15, PH_KL = 16, PH_LINE = 32 };
@@ -323,6 +331,10 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p) {
     double dg_x0 = 0, dg_mode = 0, dg_hinv1 = 0, dg_fun2 = 0, dg_init[4] = {0, 0, 0, 0}, dg_zp = 0, dg_r = 0, dg_logu = 0;
     int dg_nfev1 = 0, dg_nit1 = 0, dg_st1 = 0, dg_nfev2 = 0, dg_nit2 = 0, dg_st2 = 0, dg_acc = 0, dg_fb = 0, dg_pass = 0;
 
+#ifdef KLHR_STAMPS
+    unsigned long long stamp_t = __builtin_readcyclecounter(), st_dir = 0, st_eval = 0, st_adv = 0, st_mh = 0, st_adapt = 0, st_out = 0, st_idle = 0;
+    unsigned long long st_npass = 0;
+#endif
     for (int iter = 0; iter < p.n_iters; ++iter) {
         // =============================================================== direction (klhr_sinh.py:264)
         if (p.phases & PH_DIR) {
@@ -344,6 +356,7 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p) {
             for (int i = l8; i < D; i += 8) rg[i] = TR[i].y;
         }
 
+        KLHR_STAMP(st_dir);
         // =============================================================== fit (klhr_sinh.py:182-201)
         if (p.phases & PH_FIT) {
             Opt o;
@@ -356,6 +369,10 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p) {
             dg_pass = 0;
             for (;;) {
                 double f = 0, g[4] = {0, 0, 0, 0};
+                KLHR_STAMP(st_idle);
+#ifdef KLHR_STAMPS
+                st_npass++;
+#endif
                 if (!done) {
                     if (opt_cache_hit(o)) {
                         f = o.lf; g[0] = o.lg[0]; g[1] = o.lg[1]; g[2] = o.lg[2]; g[3] = o.lg[3];
@@ -364,6 +381,7 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p) {
                         opt_cache_store(o, f, g);
                         dg_pass++;
                     }
+                    KLHR_STAMP(st_eval);
                     opt_advance(o, f, g);
                     if (o.pc == PC_DONE) {
                         if (o.n == 1) {
@@ -384,6 +402,7 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p) {
                             done = true;
                         }
                     }
+                    KLHR_STAMP(st_adv);
                 }
                 if (__all(done)) break;
             }
@@ -405,6 +424,7 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p) {
             }
         }
 
+        KLHR_STAMP(st_idle);
         // =============================================================== MH step (klhr_sinh.py:242-260)
         if (p.phases & PH_MH) {
             draw += 1;
@@ -435,6 +455,7 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p) {
             KLHR_WAVE_SYNC();
         }
 
+        KLHR_STAMP(st_mh);
         // =============================================================== closure-or-update (klhr_sinh.py:268-287)
         if (p.phases & PH_ADAPT) {
             bool closed = false;
@@ -466,11 +487,13 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p) {
             }
         }
 
+        KLHR_STAMP(st_adapt);
         // =============================================================== outputs of this iteration
         if (p.draws) {
             double *out = p.draws + ((long long)iter * p.C + c) * D;
             for (int i = l8; i < D; i += 8) out[i] = TR[i].x;
         }
+        KLHR_STAMP(st_out);
     }
 
     // ---- store chain state
@@ -492,6 +515,10 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p) {
             dd[KLHR_D_INIT2] = dg_init[2]; dd[KLHR_D_INIT3] = dg_init[3]; dd[KLHR_D_NFEV2] = dg_nfev2; dd[KLHR_D_NIT2] = dg_nit2;
             dd[KLHR_D_STATUS2] = dg_st2; dd[KLHR_D_FUN2] = dg_fun2; dd[KLHR_D_ZP] = dg_zp; dd[KLHR_D_R] = dg_r;
             dd[KLHR_D_LOGU] = dg_logu; dd[KLHR_D_ACCEPT] = dg_acc; dd[KLHR_D_FALLBACKS] = dg_fb; dd[KLHR_D_PASSES] = dg_pass;
+#ifdef KLHR_STAMPS
+            dd[0] = (double)st_dir; dd[1] = (double)st_eval; dd[2] = (double)st_adv; dd[3] = (double)st_mh; dd[4] = (double)st_adapt;
+            dd[5] = (double)st_out; dd[6] = (double)st_idle; dd[7] = (double)st_npass;
+#endif
         }
     }
 }

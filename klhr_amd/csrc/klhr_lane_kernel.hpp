@@ -1,0 +1,407 @@
+// klhr_lane_kernel.hpp — lane-per-chain kernel for small model dimension (D <= 26).
+//
+// Why a second mapping.  Profiling the octet kernel (profiles/r01_first) showed that at D = 10 the log-density work
+// is small and the wavefront spends its instructions on per-chain *scalar* work (SciPy's optimiser logic, RNG,
+// sinh-arcsinh scalars) that the octet mapping replicates in all 8 lanes of a chain.  Here every lane owns one
+// chain (64 chains per wavefront) so nothing is replicated, and the 8 quadrature nodes of a KL evaluation become
+// 8 independent accumulator chains in registers (model_eval_nv<MODEL, 8>): one pass over the chain's LDS-resident
+// (theta_i, rho_i) pairs serves all 8 nodes, and the wavefront — alone on its SIMD at 65 536 chains per GPU, with up to
+// 512 VGPRs — gets its latency hiding from instruction-level parallelism instead of occupancy.
+//
+// Same chain-state layout in HBM, same phases / probes / diagnostics as klhr_iter_kernel: the host chooses the
+// kernel per model dimension (klhr_api.hip: use_lane_kernel), and the parity tests run both.
+//
+// LDS: per chain D double2 (theta, rho) + D doubles scratch, chain stride S ≡ 2 (mod 32) doubles so that the 16-lane
+// groups of a ds_read_b128 hit 64 distinct banks.
+#pragma once
+#include "klhr_kernels.hpp"
+
+namespace klhr {
+
+#pragma clang fp contract(off)
+// klhr_sinh.py:203-213 for the chain owned by this lane (sequential, unfused: rounds like NumPy)
+__device__ inline void lane_direction(const KParams &p, long long c, double2 *TR, const double *Z, double u_choice) {
+    const int D = p.D, nc = p.ncol;
+    const double *ev = p.eigvals + c * nc;
+    const double *evec = p.eigvecs + c * (long long)D * nc;
+    const double *cov = p.cov + c * (long long)D;
+    const int *rank = p.rank + c * (long long)D;
+    double pj[4] = {0, 0, 0, 0};
+    double sum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (j < nc) sum += ev[j];
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (j < nc) pj[j] = ev[j] / sum;
+    int pick = -1;
+    if (p.flags & FLAG_EIGEN_ONE) {
+        double cdf[4], accu = 0, last = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { accu += pj[j]; cdf[j] = accu; if (j == nc - 1) last = accu; }
+        pick = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (j < nc && cdf[j] / last <= u_choice) pick = j + 1;
+        if (pick >= nc) pick = nc - 1;
+    }
+    double nn = 0;
+    for (int i = 0; i < D; i++) {
+        double m = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (j < nc) {
+                double e = evec[i * nc + j];
+                if (pick >= 0) { if (j == pick) m = e; }
+                else m += pj[j] * e;
+            }
+        }
+        double r = m + sqrt(cov[i]) * Z[rank[i]];
+        nn += (r + p.tol) * (r + p.tol);
+        TR[i].y = r;
+    }
+    nn = sqrt(nn);
+    for (int i = 0; i < D; i++) TR[i].y = TR[i].y / nn;
+}
+
+// onlinemoments.py:10-18
+__device__ inline void lane_om_update(double *m, double *v, long long N, int D, const double2 *TR, const double *Z, bool fromZ, double clipb) {
+    const double w = 1.0 / (double)N;
+    for (int i = 0; i < D; i++) {
+        double x = fromZ ? clipc(Z[i], clipb) : TR[i].x;
+        double mi = m[i], vi = v[i];
+        double d = x - mi;
+        mi += d * w;
+        vi += -vi * w + d * d * w * (1 - w);
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
+// onlinepca.py:13-26; u = theta - mean in Z (LDS, lane-private), V rows in HBM (lane-private)
+__device__ inline void lane_pca_update(const KParams &p, long long c, long long n_new, double *Z) {
+    const int D = p.D, K = p.J;
+    double *V = p.pca_v + c * (long long)D * K;
+    const long long lim = n_new < K ? n_new : K;
+    for (int col = 0; col < lim; col++) {
+        if (col == n_new - 1) {
+            for (int i = 0; i < D; i++) V[i * K + col] = Z[i];
+        } else {
+            const double w = ((double)(n_new - 1) - p.l) / (double)n_new;
+            double s = 0, udv = 0;
+            for (int i = 0; i < D; i++) { double vi = V[i * K + col]; s += vi * vi; }
+            double nv = sqrt(s);
+            for (int i = 0; i < D; i++) udv += Z[i] * V[i * K + col];
+            for (int i = 0; i < D; i++) V[i * K + col] = w * V[i * K + col] + (1 - w) * Z[i] * udv / (nv + p.tol);
+            s = 0; udv = 0;
+            for (int i = 0; i < D; i++) { double vi = V[i * K + col]; s += vi * vi; }
+            nv = sqrt(s);
+            for (int i = 0; i < D; i++) udv += Z[i] * V[i * K + col];
+            for (int i = 0; i < D; i++) Z[i] = Z[i] - udv * V[i * K + col] / (nv * nv + p.tol);
+        }
+    }
+}
+
+// klhr_sinh.py:268-280 (+ rank permutation for the following windows)
+__device__ inline void lane_close_window(const KParams &p, long long c, long long omN, double *Z) {
+    const int D = p.D, K = p.J, nc = p.ncol;
+    double *mean = p.mean + c * (long long)D, *cov = p.cov + c * (long long)D;
+    double *om_m = p.om_m + c * (long long)D, *om_v = p.om_v + c * (long long)D;
+    double *V = p.pca_v + c * (long long)D * K;
+    double *evec = p.eigvecs + c * (long long)D * nc, *ev = p.eigvals + c * nc;
+    int *rank = p.rank + c * (long long)D;
+    for (int i = 0; i < D; i++) {
+        mean[i] = om_m[i];
+        double cv = omN > 2 ? om_v[i] * (double)omN / (double)(omN - 1) : 1.0;
+        if (p.flags & FLAG_SCALE_DIR_COV) {
+            double *omd_m = p.omd_m + c * (long long)D, *omd_v = p.omd_v + c * (long long)D;
+            double vd = omN > 2 ? omd_v[i] * (double)omN / (double)(omN - 1) : 1.0;
+            cv = cv / (p.tol + vd);
+            omd_m[i] = 0.0; omd_v[i] = 0.0;
+        }
+        cov[i] = cv;
+        Z[i] = cv;
+        om_m[i] = 0.0; om_v[i] = 0.0;
+    }
+    for (int i = 0; i < D; i++) {
+        double ci = Z[i];
+        int r = 0;
+        for (int j = 0; j < D; j++) { double cj = Z[j]; r += (cj > ci || (cj == ci && j < i)) ? 1 : 0; }
+        rank[i] = r;
+    }
+    double vals[4] = {0, 0, 0, 0};
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (j < K) {
+            double s = 0;
+            for (int i = 0; i < D; i++) { double vi = V[i * K + j]; s += vi * vi; }
+            vals[j] = sqrt(s);
+            if (!isfinite(vals[j])) bad = true;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) { if (bad) vals[j] = 0.0; vals[j] += p.tol; }
+    for (int i = 0; i < D; i++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (j < K) { evec[i * nc + j] = V[i * K + j] / vals[j]; V[i * K + j] = 0.0; }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (j < K) ev[j] = vals[j];
+}
+#pragma clang fp contract(fast)
+
+// KL(eta) value + gradient for this lane's chain: the 8 nodes in registers (klhr_sinh.py:163-176, reference order)
+template <int MODEL>
+__device__ __forceinline__ void lane_eval_kl(const KParams &p, const double2 *TR, const double *xt, double &f, double *g) {
+    const double s_ = exp(clipc(xt[1], p.scale_clip)) + p.tol;
+    const double d_ = exp(clipc(xt[2], p.scale_clip)) + p.tol;
+    const double invd = 1.0 / d_;
+    double a[8], sh[8], ch[8], t[8], logp[8], gdot[8];
+#pragma unroll
+    for (int n = 0; n < 8; n++) {
+        a[n] = (p.asx[n] + xt[3]) * invd;
+        const double ac = clipc(a[n], p.scale_clip);
+        sh[n] = sinh(ac);
+        ch[n] = cosh(ac);
+        t[n] = xt[0] + s_ * sh[n];
+    }
+    model_eval_nv<MODEL, 8>(p.md, TR, t, p.scale_clip, logp, gdot);
+    double out = 0.0, g0 = 0.0, g1 = 0.0, g2 = 0.0, g3 = 0.0;
+    const double e21 = xt[2] - xt[1];
+#pragma unroll
+    for (int n = 0; n < 8; n++) {
+        const double w = p.wq[n];
+        const double th = sh[n] / ch[n];
+        const double laj = e21 - log(ch[n]);
+        out += w * (laj - logp[n]);
+        const double wg = w * gdot[n];
+        g0 -= wg;
+        g1 -= wg * (s_ * sh[n]);                g1 += w * -1.0;
+        g2 -= wg * (-s_ * ch[n] * a[n]);        g2 += w * (1.0 + th * a[n]);
+        g3 -= wg * (s_ * ch[n] * invd);         g3 += w * (-th * invd);
+    }
+    f = out; g[0] = g0; g[1] = g1; g[2] = g2; g[3] = g3;
+}
+
+template <int MODEL>
+__device__ __forceinline__ void lane_eval_line(const KParams &p, const double2 *TR, double tv, double &f, double *g) {
+    double t[1] = {tv}, logp[1], gdot[1];
+    model_eval_nv<MODEL, 1>(p.md, TR, t, INFINITY, logp, gdot);
+    f = -logp[0]; g[0] = -gdot[0]; g[1] = g[2] = g[3] = 0.0;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int MODEL>
+__global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x & 63;
+    const long long c0 = (long long)blockIdx.x * 64;
+    const long long c = c0 + lane;
+    const bool active = c < p.C;
+    const int nch = (p.C - c0) < 64 ? (int)(p.C - c0) : 64;
+    const int D = p.D;
+    double2 *TR = reinterpret_cast<double2 *>(lds + (size_t)lane * p.S);
+    double *Z = lds + (size_t)lane * p.S + 2 * (size_t)D;
+
+    // ---- cooperative, coalesced load of the block's theta rows into LDS
+    {
+        const double *src = p.theta + c0 * (long long)D;
+        int cc = 0, i = lane;
+        while (i >= D) { i -= D; cc++; }
+        for (int idx = lane; idx < nch * D; idx += 64) {
+            double2 v; v.x = src[idx]; v.y = 0.0;
+            reinterpret_cast<double2 *>(lds + (size_t)cc * p.S)[i] = v;
+            i += 64;
+            while (i >= D) { i -= D; cc++; }
+        }
+    }
+    Pcg64 rng = {0, 0, 0, 0};
+    long long draw = 0, omN = 0, pcan = 0, gevals = 0;
+    int cidx = 0;
+    double acc = 0;
+    if (active) {
+        rng.sh = p.rng[c * 4 + 0]; rng.sl = p.rng[c * 4 + 1]; rng.ih = p.rng[c * 4 + 2]; rng.il = p.rng[c * 4 + 3];
+        draw = p.counters[c * 4 + 0]; omN = p.counters[c * 4 + 1]; pcan = p.counters[c * 4 + 2]; cidx = (int)p.counters[c * 4 + 3];
+        acc = p.acc[c];
+        gevals = p.grad_evals[c];
+    }
+    KLHR_WAVE_SYNC();
+
+    double eta[4] = {0, 0, 0, 0};
+    double dg_x0 = 0, dg_mode = 0, dg_hinv1 = 0, dg_fun2 = 0, dg_init[4] = {0, 0, 0, 0}, dg_zp = 0, dg_r = 0, dg_logu = 0;
+    int dg_nfev1 = 0, dg_nit1 = 0, dg_st1 = 0, dg_nfev2 = 0, dg_nit2 = 0, dg_st2 = 0, dg_acc = 0, dg_fb = 0, dg_pass = 0;
+
+    for (int iter = 0; iter < p.n_iters; ++iter) {
+        // =============================================================== direction
+        if (active) {
+            if (p.phases & PH_DIR) {
+                const double u_choice = (p.flags & FLAG_EIGEN_ONE) ? pcg_next_double(rng) : 0.0;
+                for (int k = 0; k < D; k++) Z[k] = rng_std_normal(rng);
+                lane_direction(p, c, TR, Z, u_choice);
+                if (p.flags & FLAG_DIAG) {
+                    double *rg = p.d_rho + c * (long long)D;
+                    for (int i = 0; i < D; i++) rg[i] = TR[i].y;
+                }
+            } else {
+                const double *rg = p.d_rho + c * (long long)D;
+                for (int i = 0; i < D; i++) TR[i].y = rg[i];
+            }
+        }
+
+        // =============================================================== fit
+        if (p.phases & PH_FIT) {
+            Opt o;
+            {
+                double x0v[4] = {0, 0, 0, 0};
+                if (active) x0v[0] = rng_std_normal(rng) * p.initscale;
+                dg_x0 = x0v[0];
+                opt_begin(o, 1, x0v, 1e-5);
+            }
+            bool done = !active;
+            dg_pass = 0;
+            for (;;) {
+                double f = 0, g[4] = {0, 0, 0, 0};
+                const bool hit = !done && opt_cache_hit(o);
+                const bool ev1 = !done && !hit && o.n == 1;
+                const bool ev4 = !done && !hit && o.n == 4;
+                if (ev1) lane_eval_line<MODEL>(p, TR, o.xt[0], f, g);
+                if (ev4) lane_eval_kl<MODEL>(p, TR, o.xt, f, g);
+                if (!done) {
+                    if (hit) { f = o.lf; g[0] = o.lg[0]; g[1] = o.lg[1]; g[2] = o.lg[2]; g[3] = o.lg[3]; }
+                    else { opt_cache_store(o, f, g); dg_pass++; }
+                    opt_advance(o, f, g);
+                    if (o.pc == PC_DONE) {
+                        if (o.n == 1) {
+                            gevals += o.nfev;
+                            dg_mode = o.xk[0]; dg_hinv1 = o.H[0]; dg_nfev1 = o.nfev; dg_nit1 = o.k; dg_st1 = o.status; dg_fb = o.fallbacks;
+                            double s = o.H[0];
+                            s = (s > 0 ? 1.0 : 0.0) * 0.5 * log(s);
+                            double init[4];
+                            for (int k = 0; k < 4; k++) init[k] = rng_std_normal(rng) * p.initscale;
+                            init[0] = o.xk[0];
+                            init[1] = s;
+                            for (int k = 0; k < 4; k++) dg_init[k] = init[k];
+                            opt_begin(o, 4, init, 1e-3);
+                        } else {
+                            gevals += (long long)o.nfev * 8;
+                            for (int k = 0; k < 4; k++) eta[k] = o.xk[k];
+                            dg_nfev2 = o.nfev; dg_nit2 = o.k; dg_st2 = o.status; dg_fun2 = o.old_fval; dg_fb += o.fallbacks;
+                            done = true;
+                        }
+                    }
+                }
+                if (__all(done)) break;
+            }
+            if (active && (p.flags & FLAG_DIAG)) {
+                for (int k = 0; k < 4; k++) p.d_eta[c * 4 + k] = eta[k];
+            }
+        } else if (active) {
+            for (int k = 0; k < 4; k++) eta[k] = p.d_eta[c * 4 + k];
+        }
+
+        // =============================================================== KL / line probes
+        if ((p.phases & (PH_KL | PH_LINE)) && active) {
+            double f, g[4];
+            if (p.phases & PH_KL) lane_eval_kl<MODEL>(p, TR, eta, f, g);
+            else lane_eval_line<MODEL>(p, TR, eta[0], f, g);
+            double *dd = p.d_diag + c * KLHR_NDIAG;
+            dd[0] = f; dd[1] = g[0]; dd[2] = g[1]; dd[3] = g[2]; dd[4] = g[3];
+        }
+
+        // =============================================================== MH step
+        if ((p.phases & PH_MH) && active) {
+            draw += 1;
+            const double z = rng_std_normal(rng);
+            const double zp = sa_T(z, eta, p.tol, p.scale_clip);
+            double t2[2] = {zp, 0.0}, lp2[2], gd2[2];
+            model_eval_nv<MODEL, 2>(p.md, TR, t2, INFINITY, lp2, gd2);
+            double r = lp2[0];
+            r -= lp2[1];
+            r += sa_log_q(0.0, eta, p.tol, p.scale_clip);
+            r -= sa_log_q(zp, eta, p.tol, p.scale_clip);
+            const double logu = log(rng_uniform(rng));
+            const double mn = (r != r) ? r : (r < 0 ? r : 0.0);
+            const int a = logu < mn ? 1 : 0;
+            const double ad = (double)a, na = (double)(1 - a);
+            for (int i = 0; i < D; i++) {
+                double2 v = TR[i];
+                double thp = __dadd_rn(__dmul_rn(zp, v.y), v.x);
+                v.x = __dadd_rn(__dmul_rn(ad, thp), __dmul_rn(na, v.x));
+                TR[i] = v;
+            }
+            acc += (ad - acc) / (double)draw;
+            dg_zp = zp; dg_r = r; dg_logu = logu; dg_acc = a;
+        }
+
+        // =============================================================== closure-or-update
+        if ((p.phases & PH_ADAPT) && active) {
+            bool closed = false;
+            if (!(p.warmup < p.windowsize) && p.nclos > 0) {
+                closed = draw == p.closures[cidx];
+                if (closed && cidx < p.nclos - 1) cidx++;
+            }
+            if (closed) {
+                lane_close_window(p, c, omN, Z);
+                omN = 0;
+                pcan = 0;
+            } else {
+                omN += 1;
+                if (p.flags & FLAG_SCALE_DIR_COV) {
+                    double lp_, gd_;
+                    model_eval<MODEL>(p.md, [&](int i, double &xi, double &ri) { xi = TR[i].x; ri = 0.0; }, INFINITY,
+                                      [&](int i, double gi) { Z[i] = gi; }, lp_, gd_);
+                    lane_om_update(p.omd_m + c * (long long)D, p.omd_v + c * (long long)D, omN, D, TR, Z, true, p.scale_clip);
+                }
+                lane_om_update(p.om_m + c * (long long)D, p.om_v + c * (long long)D, omN, D, TR, Z, false, 0.0);
+                const double *mean = p.mean + c * (long long)D;
+                for (int i = 0; i < D; i++) Z[i] = __dsub_rn(TR[i].x, mean[i]);
+                pcan += 1;
+                lane_pca_update(p, c, pcan, Z);
+            }
+        }
+
+        // =============================================================== draws: cooperative, coalesced store
+        if (p.draws) {
+            KLHR_WAVE_SYNC();
+            double *dst = p.draws + ((long long)iter * p.C + c0) * D;
+            int cc = 0, i = lane;
+            while (i >= D) { i -= D; cc++; }
+            for (int idx = lane; idx < nch * D; idx += 64) {
+                dst[idx] = reinterpret_cast<const double2 *>(lds + (size_t)cc * p.S)[i].x;
+                i += 64;
+                while (i >= D) { i -= D; cc++; }
+            }
+            KLHR_WAVE_SYNC();
+        }
+    }
+
+    // ---- store chain state
+    KLHR_WAVE_SYNC();
+    {
+        double *dst = p.theta + c0 * (long long)D;
+        int cc = 0, i = lane;
+        while (i >= D) { i -= D; cc++; }
+        for (int idx = lane; idx < nch * D; idx += 64) {
+            dst[idx] = reinterpret_cast<const double2 *>(lds + (size_t)cc * p.S)[i].x;
+            i += 64;
+            while (i >= D) { i -= D; cc++; }
+        }
+    }
+    if (active) {
+        bool fin = true;
+        for (int i = 0; i < D; i++) if (!isfinite(TR[i].x)) fin = false;
+        if (!fin) atomicOr(&p.status[c], 2);
+        p.rng[c * 4 + 0] = rng.sh; p.rng[c * 4 + 1] = rng.sl; p.rng[c * 4 + 2] = rng.ih; p.rng[c * 4 + 3] = rng.il;
+        p.counters[c * 4 + 0] = draw; p.counters[c * 4 + 1] = omN; p.counters[c * 4 + 2] = pcan; p.counters[c * 4 + 3] = cidx;
+        p.acc[c] = acc;
+        p.grad_evals[c] = gevals;
+        if ((p.flags & FLAG_DIAG) && !(p.phases & (PH_KL | PH_LINE))) {
+            double *dd = p.d_diag + c * KLHR_NDIAG;
+            dd[KLHR_D_X0] = dg_x0; dd[KLHR_D_MODE] = dg_mode; dd[KLHR_D_HINV1] = dg_hinv1; dd[KLHR_D_NFEV1] = dg_nfev1;
+            dd[KLHR_D_NIT1] = dg_nit1; dd[KLHR_D_STATUS1] = dg_st1; dd[KLHR_D_INIT0] = dg_init[0]; dd[KLHR_D_INIT1] = dg_init[1];
+            dd[KLHR_D_INIT2] = dg_init[2]; dd[KLHR_D_INIT3] = dg_init[3]; dd[KLHR_D_NFEV2] = dg_nfev2; dd[KLHR_D_NIT2] = dg_nit2;
+            dd[KLHR_D_STATUS2] = dg_st2; dd[KLHR_D_FUN2] = dg_fun2; dd[KLHR_D_ZP] = dg_zp; dd[KLHR_D_R] = dg_r;
+            dd[KLHR_D_LOGU] = dg_logu; dd[KLHR_D_ACCEPT] = dg_acc; dd[KLHR_D_FALLBACKS] = dg_fb; dd[KLHR_D_PASSES] = dg_pass;
+        }
+    }
+}
+
+}  // namespace klhr
