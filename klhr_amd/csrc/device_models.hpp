@@ -126,6 +126,13 @@ __device__ __forceinline__ void model_eval(const ModelData &md, XR xr, double cl
 // Per point the arithmetic and its order are exactly those of model_eval above.
 namespace klhr {
 
+// clip for accumulation loops: v_max/v_min (2 instructions instead of 6) drop NaNs, so NaN-ness is tracked on the side
+// and re-applied to the sum — the result equals sum(np.clip(g) * rho) including NaN propagation.
+__device__ __forceinline__ double clip_acc(double x, double c, bool &sawnan) {
+    sawnan = sawnan || (x != x);
+    return fmin(fmax(x, -c), c);
+}
+
 template <int MODEL, int NV>
 __device__ __forceinline__ void model_eval_nv(const ModelData &md, const double2 *TR, const double (&t)[NV], double cl,
                                               double (&logp)[NV], double (&gdot)[NV]) {
@@ -133,18 +140,44 @@ __device__ __forceinline__ void model_eval_nv(const ModelData &md, const double2
     if constexpr (MODEL == MODEL_FUNNEL) {
         const double2 e0 = TR[0];
         const double Da = (double)md.n;
-        double v[NV], ev[NV], ss[NV], gd[NV];
+        double v[NV], ev[NV], ss[NV], gd[NV], big[NV];
 #pragma unroll
-        for (int n = 0; n < NV; n++) { v[n] = fma(t[n], e0.y, e0.x); ev[n] = exp(-v[n]); ss[n] = 0.0; gd[n] = 0.0; }
+        for (int n = 0; n < NV; n++) { v[n] = fma(t[n], e0.y, e0.x); ev[n] = exp(-v[n]); ss[n] = 0.0; gd[n] = 0.0; big[n] = 0.0; }
+        // Fast path: accumulate the UNclipped gradient.rho and remember the largest |g_i|; if no component of any
+        // lane exceeds the clip bound (the overwhelmingly common case) that sum IS sum(clip(g_i) rho_i), bit for bit.
+        // Otherwise the clipped sum is recomputed below (same order), so results never depend on which path ran.
+        double2 e = TR[D > 1 ? 1 : 0];
         for (int i = 1; i < D; i++) {
-            const double2 e = TR[i];
+            const double2 en = TR[i + 1 < D ? i + 1 : i];      // software prefetch: hide the LDS latency
 #pragma unroll
             for (int n = 0; n < NV; n++) {
                 double xi = fma(t[n], e.y, e.x);
                 ss[n] += xi * xi;
                 double gi = -ev[n] * xi;
-                gd[n] += clipc(gi, cl) * e.y;
+                big[n] = fmax(big[n], fabs(gi));
+                gd[n] += gi * e.y;
             }
+            e = en;
+        }
+        bool need_clip = false;
+#pragma unroll
+        for (int n = 0; n < NV; n++) need_clip = need_clip || !(big[n] <= cl) ;
+        // NaN components: fmax drops them, but then gd is NaN as well, exactly as np.clip would leave it
+        if (__any(need_clip)) {
+            bool nanf[NV];
+#pragma unroll
+            for (int n = 0; n < NV; n++) { gd[n] = 0.0; nanf[n] = false; }
+            for (int i = 1; i < D; i++) {
+                const double2 ee = TR[i];
+#pragma unroll
+                for (int n = 0; n < NV; n++) {
+                    double xi = fma(t[n], ee.y, ee.x);
+                    double gi = -ev[n] * xi;
+                    gd[n] += clip_acc(gi, cl, nanf[n]) * ee.y;
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < NV; n++) if (nanf[n]) gd[n] = NAN;
         }
 #pragma unroll
         for (int n = 0; n < NV; n++) {
@@ -154,8 +187,9 @@ __device__ __forceinline__ void model_eval_nv(const ModelData &md, const double2
         }
     } else if constexpr (MODEL == MODEL_ILL_NORMAL || MODEL == MODEL_NORMAL) {
         double acc[NV], gd[NV];
+        bool nanf[NV];
 #pragma unroll
-        for (int n = 0; n < NV; n++) { acc[n] = 0.0; gd[n] = 0.0; }
+        for (int n = 0; n < NV; n++) { acc[n] = 0.0; gd[n] = 0.0; nanf[n] = false; }
         for (int i = 0; i < D; i++) {
             const double2 e = TR[i];
             const double is = (MODEL == MODEL_ILL_NORMAL) ? md.aux[i] : 1.0;
@@ -165,11 +199,11 @@ __device__ __forceinline__ void model_eval_nv(const ModelData &md, const double2
                 double gi;
                 if constexpr (MODEL == MODEL_ILL_NORMAL) { double z = xi * is; acc[n] += z * z; gi = -z * is; }
                 else { acc[n] += xi * xi; gi = -xi; }
-                gd[n] += clipc(gi, cl) * e.y;
+                gd[n] += clip_acc(gi, cl, nanf[n]) * e.y;
             }
         }
 #pragma unroll
-        for (int n = 0; n < NV; n++) { gdot[n] = gd[n]; logp[n] = -0.5 * acc[n]; }
+        for (int n = 0; n < NV; n++) { gdot[n] = nanf[n] ? NAN : gd[n]; logp[n] = -0.5 * acc[n]; }
     } else {   // MODEL_GLMM_POISSON
         const int nn = md.n;
         const double *x1 = md.aux, *x2 = md.aux + nn, *x3 = md.aux + 2 * nn, *Cn = md.aux + 3 * nn;
