@@ -140,12 +140,17 @@ __device__ __forceinline__ void model_eval_nv(const ModelData &md, const double2
     if constexpr (MODEL == MODEL_FUNNEL) {
         const double2 e0 = TR[0];
         const double Da = (double)md.n;
-        double v[NV], ev[NV], ss[NV], gd[NV], big[NV];
+        double v[NV], ev[NV], ss[NV], gd[NV];
+        bool odd = false;
 #pragma unroll
-        for (int n = 0; n < NV; n++) { v[n] = fma(t[n], e0.y, e0.x); ev[n] = exp(-v[n]); ss[n] = 0.0; gd[n] = 0.0; big[n] = 0.0; }
-        // Fast path: accumulate the UNclipped gradient.rho and remember the largest |g_i|; if no component of any
-        // lane exceeds the clip bound (the overwhelmingly common case) that sum IS sum(clip(g_i) rho_i), bit for bit.
-        // Otherwise the clipped sum is recomputed below (same order), so results never depend on which path ran.
+        for (int n = 0; n < NV; n++) {
+            v[n] = fma(t[n], e0.y, e0.x); ev[n] = exp(-v[n]); ss[n] = 0.0; gd[n] = 0.0;
+            odd = odd || !(ev[n] > 0.0 && ev[n] < INFINITY);
+        }
+        // Hot loop: clip with v_max/v_min (which drop NaNs).  While exp(-v) is finite and positive, g_i = -exp(-v) xi is
+        // NaN exactly when xi is NaN, i.e. exactly when ss ends up NaN, so NaN-ness is restored after the loop; the
+        // (rare) lanes with exp(-v) in {0, inf, NaN} take the careful loop below.  Either way the value equals
+        // sum_i np.clip(g_i) rho_i accumulated in index order.
         double2 e = TR[D > 1 ? 1 : 0];
         for (int i = 1; i < D; i++) {
             const double2 en = TR[i + 1 < D ? i + 1 : i];      // software prefetch: hide the LDS latency
@@ -154,16 +159,13 @@ __device__ __forceinline__ void model_eval_nv(const ModelData &md, const double2
                 double xi = fma(t[n], e.y, e.x);
                 ss[n] += xi * xi;
                 double gi = -ev[n] * xi;
-                big[n] = fmax(big[n], fabs(gi));
-                gd[n] += gi * e.y;
+                gd[n] += fmin(fmax(gi, -cl), cl) * e.y;
             }
             e = en;
         }
-        bool need_clip = false;
 #pragma unroll
-        for (int n = 0; n < NV; n++) need_clip = need_clip || !(big[n] <= cl) ;
-        // NaN components: fmax drops them, but then gd is NaN as well, exactly as np.clip would leave it
-        if (__any(need_clip)) {
+        for (int n = 0; n < NV; n++) if (ss[n] != ss[n]) gd[n] = NAN;
+        if (__any(odd)) {
             bool nanf[NV];
 #pragma unroll
             for (int n = 0; n < NV; n++) { gd[n] = 0.0; nanf[n] = false; }

@@ -225,7 +225,7 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
     k.C = s->C; k.D = D; k.S = S; k.ncol = s->ncol; k.J = cfg->J;
     k.flags = (cfg->scale_dir_cov ? FLAG_SCALE_DIR_COV : 0) | (cfg->eigen_method_one ? FLAG_EIGEN_ONE : 0);
     k.tol = cfg->tol; k.scale_clip = cfg->scale_clip; k.initscale = cfg->initscale; k.l = cfg->l;
-    for (int i = 0; i < 8; i++) { k.xq[i] = cfg->quad_x[i]; k.wq[i] = cfg->quad_w[i]; k.asx[i] = cfg->quad_asinh_x[i]; }
+    for (int i = 0; i < 8; i++) { k.wq[i] = cfg->quad_w[i]; k.asx[i] = cfg->quad_asinh_x[i]; }
     TRY(dalloc(s, &s->d_aux, aux.size()));
     if (!aux.empty()) TRY(hip_try(hipMemcpy(s->d_aux, aux.data(), aux.size() * 8, hipMemcpyHostToDevice), "hipMemcpy aux"));
     k.md.aux = s->d_aux; k.md.D = D; k.md.n = n;
@@ -241,7 +241,14 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
     int ncl = klhr_window_closures(cfg->warmup, cfg->windowsize, cfg->windowscale, cl, 40);
     if (ncl > 40) { s->err = "klhr_create: more than 40 adaptation windows"; return bail(KLHR_ERR_ARG); }
     k.nclos = ncl;
-    for (int i = 0; i < ncl; i++) k.closures[i] = cl[i];
+    {
+        long long *d_cl = nullptr;
+        TRY(dalloc(s, &d_cl, 40));
+        long long hcl[40] = {0};
+        for (int i = 0; i < ncl; i++) hcl[i] = cl[i];
+        TRY(hip_try(hipMemcpy(d_cl, hcl, sizeof hcl, hipMemcpyHostToDevice), "hipMemcpy closures"));
+        k.closures = d_cl;
+    }
     TRY(reset_state(s));
 #undef TRY
     *out = s;

@@ -40,7 +40,7 @@ struct KParams {
     int C, D, S, ncol, J, flags, phases, n_iters;
     ModelData md;
     double tol, scale_clip, initscale, l;
-    double xq[8], wq[8], asx[8];
+    double wq[8], asx[8];      // quadrature weights and asinh(node) (nodes themselves are not needed on the device)
     double *theta;
     uint64_t *rng;
     double *mean, *cov, *eigvecs, *eigvals, *om_m, *om_v, *omd_m, *omd_v, *pca_v, *acc;
@@ -52,7 +52,7 @@ struct KParams {
     double *draws;            // [n_iters][C][D] or nullptr
     long long warmup, windowsize;
     int nclos;
-    long long closures[40];
+    const long long *closures;   // device array of window-closure draw indices
 };
 
 __device__ __forceinline__ double grp_sum8(double v) {
@@ -389,10 +389,13 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p) {
                             dg_mode = o.xk[0]; dg_hinv1 = o.H[0]; dg_nfev1 = o.nfev; dg_nit1 = o.k; dg_st1 = o.status; dg_fb = o.fallbacks;
                             double s = o.H[0];
                             s = (s > 0 ? 1.0 : 0.0) * 0.5 * log(s);
-                            double init[4];
-                            for (int k = 0; k < 4; k++) init[k] = rng_std_normal(rng) * p.initscale;
-                            init[0] = o.xk[0];
-                            init[1] = s;
+                            // init = rng.normal(size=4) * initscale, then [0], [1] overwritten (klhr_sinh.py:191-193):
+                            // four normals are consumed, the first two discarded (no loop: keeps init[] in registers)
+                            (void)rng_std_normal(rng);
+                            (void)rng_std_normal(rng);
+                            const double n2 = rng_std_normal(rng) * p.initscale;
+                            const double n3 = rng_std_normal(rng) * p.initscale;
+                            double init[4] = {o.xk[0], s, n2, n3};
                             for (int k = 0; k < 4; k++) dg_init[k] = init[k];
                             opt_begin(o, 4, init, 1e-3);
                         } else {

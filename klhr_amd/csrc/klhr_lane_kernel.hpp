@@ -238,8 +238,9 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
     KLHR_WAVE_SYNC();
 
     double eta[4] = {0, 0, 0, 0};
-    double dg_x0 = 0, dg_mode = 0, dg_hinv1 = 0, dg_fun2 = 0, dg_init[4] = {0, 0, 0, 0}, dg_zp = 0, dg_r = 0, dg_logu = 0;
-    int dg_nfev1 = 0, dg_nit1 = 0, dg_st1 = 0, dg_nfev2 = 0, dg_nit2 = 0, dg_st2 = 0, dg_acc = 0, dg_fb = 0, dg_pass = 0;
+    // diagnostics go straight to memory when requested (wave-uniform flag): they are not carried in registers
+    const bool diag = (p.flags & FLAG_DIAG) && !(p.phases & (PH_KL | PH_LINE));
+    double *dd = p.d_diag + (active ? c : 0) * KLHR_NDIAG;
 
     for (int iter = 0; iter < p.n_iters; ++iter) {
         // =============================================================== direction
@@ -264,11 +265,11 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
             {
                 double x0v[4] = {0, 0, 0, 0};
                 if (active) x0v[0] = rng_std_normal(rng) * p.initscale;
-                dg_x0 = x0v[0];
+                if (diag && active) dd[KLHR_D_X0] = x0v[0];
                 opt_begin(o, 1, x0v, 1e-5);
             }
             bool done = !active;
-            dg_pass = 0;
+            int npass = 0;
             for (;;) {
                 double f = 0, g[4] = {0, 0, 0, 0};
                 const bool hit = !done && opt_cache_hit(o);
@@ -278,24 +279,33 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
                 if (ev4) lane_eval_kl<MODEL>(p, TR, o.xt, f, g);
                 if (!done) {
                     if (hit) { f = o.lf; g[0] = o.lg[0]; g[1] = o.lg[1]; g[2] = o.lg[2]; g[3] = o.lg[3]; }
-                    else { opt_cache_store(o, f, g); dg_pass++; }
+                    else { opt_cache_store(o, f, g); npass++; }
                     opt_advance(o, f, g);
                     if (o.pc == PC_DONE) {
                         if (o.n == 1) {
                             gevals += o.nfev;
-                            dg_mode = o.xk[0]; dg_hinv1 = o.H[0]; dg_nfev1 = o.nfev; dg_nit1 = o.k; dg_st1 = o.status; dg_fb = o.fallbacks;
+                            if (diag) {
+                                dd[KLHR_D_MODE] = o.xk[0]; dd[KLHR_D_HINV1] = o.H[0]; dd[KLHR_D_NFEV1] = o.nfev; dd[KLHR_D_NIT1] = o.k;
+                                dd[KLHR_D_STATUS1] = o.status; dd[KLHR_D_FALLBACKS] = o.fallbacks;
+                            }
                             double s = o.H[0];
                             s = (s > 0 ? 1.0 : 0.0) * 0.5 * log(s);
-                            double init[4];
-                            for (int k = 0; k < 4; k++) init[k] = rng_std_normal(rng) * p.initscale;
-                            init[0] = o.xk[0];
-                            init[1] = s;
-                            for (int k = 0; k < 4; k++) dg_init[k] = init[k];
+                            // init = rng.normal(size=4) * initscale, then [0], [1] overwritten (klhr_sinh.py:191-193):
+                            // four normals are consumed, the first two discarded (no loop: keeps init[] in registers)
+                            (void)rng_std_normal(rng);
+                            (void)rng_std_normal(rng);
+                            const double n2 = rng_std_normal(rng) * p.initscale;
+                            const double n3 = rng_std_normal(rng) * p.initscale;
+                            double init[4] = {o.xk[0], s, n2, n3};
+                            if (diag) { dd[KLHR_D_INIT0] = init[0]; dd[KLHR_D_INIT1] = init[1]; dd[KLHR_D_INIT2] = init[2]; dd[KLHR_D_INIT3] = init[3]; }
                             opt_begin(o, 4, init, 1e-3);
                         } else {
                             gevals += (long long)o.nfev * 8;
                             for (int k = 0; k < 4; k++) eta[k] = o.xk[k];
-                            dg_nfev2 = o.nfev; dg_nit2 = o.k; dg_st2 = o.status; dg_fun2 = o.old_fval; dg_fb += o.fallbacks;
+                            if (diag) {
+                                dd[KLHR_D_NFEV2] = o.nfev; dd[KLHR_D_NIT2] = o.k; dd[KLHR_D_STATUS2] = o.status; dd[KLHR_D_FUN2] = o.old_fval;
+                                dd[KLHR_D_FALLBACKS] += o.fallbacks; dd[KLHR_D_PASSES] = npass;
+                            }
                             done = true;
                         }
                     }
@@ -314,8 +324,8 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
             double f, g[4];
             if (p.phases & PH_KL) lane_eval_kl<MODEL>(p, TR, eta, f, g);
             else lane_eval_line<MODEL>(p, TR, eta[0], f, g);
-            double *dd = p.d_diag + c * KLHR_NDIAG;
-            dd[0] = f; dd[1] = g[0]; dd[2] = g[1]; dd[3] = g[2]; dd[4] = g[3];
+            double *dp = p.d_diag + c * KLHR_NDIAG;
+            dp[0] = f; dp[1] = g[0]; dp[2] = g[1]; dp[3] = g[2]; dp[4] = g[3];
         }
 
         // =============================================================== MH step
@@ -340,7 +350,7 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
                 TR[i] = v;
             }
             acc += (ad - acc) / (double)draw;
-            dg_zp = zp; dg_r = r; dg_logu = logu; dg_acc = a;
+            if (diag) { dd[KLHR_D_ZP] = zp; dd[KLHR_D_R] = r; dd[KLHR_D_LOGU] = logu; dd[KLHR_D_ACCEPT] = a; }
         }
 
         // =============================================================== closure-or-update
@@ -405,14 +415,6 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
         p.counters[c * 4 + 0] = draw; p.counters[c * 4 + 1] = omN; p.counters[c * 4 + 2] = pcan; p.counters[c * 4 + 3] = cidx;
         p.acc[c] = acc;
         p.grad_evals[c] = gevals;
-        if ((p.flags & FLAG_DIAG) && !(p.phases & (PH_KL | PH_LINE))) {
-            double *dd = p.d_diag + c * KLHR_NDIAG;
-            dd[KLHR_D_X0] = dg_x0; dd[KLHR_D_MODE] = dg_mode; dd[KLHR_D_HINV1] = dg_hinv1; dd[KLHR_D_NFEV1] = dg_nfev1;
-            dd[KLHR_D_NIT1] = dg_nit1; dd[KLHR_D_STATUS1] = dg_st1; dd[KLHR_D_INIT0] = dg_init[0]; dd[KLHR_D_INIT1] = dg_init[1];
-            dd[KLHR_D_INIT2] = dg_init[2]; dd[KLHR_D_INIT3] = dg_init[3]; dd[KLHR_D_NFEV2] = dg_nfev2; dd[KLHR_D_NIT2] = dg_nit2;
-            dd[KLHR_D_STATUS2] = dg_st2; dd[KLHR_D_FUN2] = dg_fun2; dd[KLHR_D_ZP] = dg_zp; dd[KLHR_D_R] = dg_r;
-            dd[KLHR_D_LOGU] = dg_logu; dd[KLHR_D_ACCEPT] = dg_acc; dd[KLHR_D_FALLBACKS] = dg_fb; dd[KLHR_D_PASSES] = dg_pass;
-        }
     }
 }
 

@@ -1,5 +1,5 @@
 import csv,glob,collections
-f=sorted(glob.glob("gpurun_out/pmc_ph/*/*_counter_collection.csv"))[-1]
+import os; f=max(glob.glob("gpurun_out/pmc_ph/*/*_counter_collection.csv"),key=os.path.getmtime)
 rows=[r for r in csv.DictReader(open(f)) if 'lane_kernel' in r['Kernel_Name'] or 'iter_kernel' in r['Kernel_Name']]
 by=collections.OrderedDict()
 for r in rows: by.setdefault(int(r['Dispatch_Id']),{})[r['Counter_Name']]=float(r['Counter_Value'])
