@@ -151,17 +151,24 @@ __device__ __forceinline__ void model_eval_nv(const ModelData &md, const double2
         // NaN exactly when xi is NaN, i.e. exactly when ss ends up NaN, so NaN-ness is restored after the loop; the
         // (rare) lanes with exp(-v) in {0, inf, NaN} take the careful loop below.  Either way the value equals
         // sum_i np.clip(g_i) rho_i accumulated in index order.
-        double2 e = TR[D > 1 ? 1 : 0];
-        for (int i = 1; i < D; i++) {
-            const double2 en = TR[i + 1 < D ? i + 1 : i];      // software prefetch: hide the LDS latency
+        // coordinates are fetched from LDS three at a time (one wait per chunk instead of one per coordinate)
+        for (int i = 1; i < D; i += 3) {
+            const double2 ea = TR[i];
+            const double2 eb = TR[i + 1 < D ? i + 1 : i];
+            const double2 ec = TR[i + 2 < D ? i + 2 : i];
 #pragma unroll
-            for (int n = 0; n < NV; n++) {
-                double xi = fma(t[n], e.y, e.x);
-                ss[n] += xi * xi;
-                double gi = -ev[n] * xi;
-                gd[n] += fmin(fmax(gi, -cl), cl) * e.y;
+            for (int k = 0; k < 3; k++) {
+                if (i + k < D) {
+                    const double2 e = k == 0 ? ea : (k == 1 ? eb : ec);
+#pragma unroll
+                    for (int n = 0; n < NV; n++) {
+                        double xi = fma(t[n], e.y, e.x);
+                        ss[n] += xi * xi;
+                        double gi = -ev[n] * xi;
+                        gd[n] += fmin(fmax(gi, -cl), cl) * e.y;
+                    }
+                }
             }
-            e = en;
         }
 #pragma unroll
         for (int n = 0; n < NV; n++) if (ss[n] != ss[n]) gd[n] = NAN;
