@@ -69,8 +69,9 @@ __device__ __forceinline__ void opt_request(Opt &o, double a) {
 }
 
 // _dcsrch.py:502-728
-__device__ inline void dcstep(double &stx, double &fx, double &dx, double &sty, double &fy, double &dy, double &stp,
-                              double fp, double dp, bool &brackt, double stpmin, double stpmax) {
+// (force-inlined at its single call site: by-reference arguments of an out-of-line copy would live in scratch memory)
+__device__ __forceinline__ void dcstep(double &stx, double &fx, double &dx, double &sty, double &fy, double &dy, double &stp,
+                                       double fp, double dp, bool &brackt, double stpmin, double stpmax) {
     const double sgnd = npsign(dp) * npsign(dx);
     double theta, s, gamma, p, q, r, stpc, stpq, stpf;
     if (fp > fx) {
@@ -131,16 +132,16 @@ __device__ inline void dcstep(double &stx, double &fx, double &dx, double &sty, 
         } else if (stp > stx) stpf = stpmax;
         else stpf = stpmin;
     }
-    if (fp > fx) { sty = stp; fy = fp; dy = dp; }
-    else {
-        if (sgnd < 0) { sty = stx; fy = fx; dy = dx; }
-        stx = stp; fx = fp; dx = dp;
-    }
+    // interval update (_dcsrch.py:713-726), written as value selects so that the by-reference state stays in registers
+    const bool up = fp > fx, sw = sgnd < 0;
+    const double n_sty = up ? stp : (sw ? stx : sty), n_fy = up ? fp : (sw ? fx : fy), n_dy = up ? dp : (sw ? dx : dy);
+    const double n_stx = up ? stx : stp, n_fx = up ? fx : fp, n_dx = up ? dx : dp;
+    stx = n_stx; fx = n_fx; dx = n_dx; sty = n_sty; fy = n_fy; dy = n_dy;
     stp = stpf;
 }
 
 // _linesearch.py:503-549 — "None" (errstate raise / non-finite) is returned as false
-__device__ inline bool cubicmin(double a, double fa, double fpa, double b, double fb, double c, double fc, double &xmin) {
+__device__ __forceinline__ bool cubicmin(double a, double fa, double fpa, double b, double fb, double c, double fc, double &xmin) {
     double C = fpa, db = b - a, dc = c - a;
     double denom = (db * dc) * (db * dc) * (db - dc);
     double d00 = dc * dc, d01 = -(db * db), d10 = -(dc * dc * dc), d11 = db * db * db;
@@ -155,7 +156,7 @@ __device__ inline bool cubicmin(double a, double fa, double fpa, double b, doubl
     xmin = x;
     return true;
 }
-__device__ inline bool quadmin(double a, double fa, double fpa, double b, double fb, double &xmin) {
+__device__ __forceinline__ bool quadmin(double a, double fa, double fpa, double b, double fb, double &xmin) {
     double D = fa, C = fpa, db = b - a * 1.0;
     if (db * db == 0.0) return false;
     double B = (fb - D - C * db) / (db * db);
@@ -245,14 +246,16 @@ __device__ inline void opt_advance(Opt &o, double f, const double *g) {
             else if (task == 2) act = A_W2START;
             else {
                 double stx = o.ls[L_STX], fx = o.ls[L_FX], gx = o.ls[L_GX], sty = o.ls[L_STY], fy = o.ls[L_FY], gy = o.ls[L_GY];
-                if (!o.stage2 && f <= fx && f > ftest) {
-                    double fm = f - stp * gtest, fxm = fx - stx * gtest, fym = fy - sty * gtest;
-                    double gm = dphi - gtest, gxm = gx - gtest, gym = gy - gtest;
-                    dcstep(stx, fxm, gxm, sty, fym, gym, stp, fm, gm, o.brackt, o.ls[L_STMIN], o.ls[L_STMAX]);
-                    fx = fxm + stx * gtest; fy = fym + sty * gtest; gx = gxm + gtest; gy = gym + gtest;
-                } else {
-                    dcstep(stx, fx, gx, sty, fy, gy, stp, f, dphi, o.brackt, o.ls[L_STMIN], o.ls[L_STMAX]);
+                // stage 1 works on the modified function psi(stp) = f(stp) - f(0) - ftol*stp*f'(0) (_dcsrch.py:401-441);
+                // one dcstep call serves both branches, with the modification applied / removed around it
+                const bool mod = !o.stage2 && f <= fx && f > ftest;
+                double fpa = f, dpa = dphi;
+                if (mod) {
+                    fpa = f - stp * gtest; fx = fx - stx * gtest; fy = fy - sty * gtest;
+                    dpa = dphi - gtest; gx = gx - gtest; gy = gy - gtest;
                 }
+                dcstep(stx, fx, gx, sty, fy, gy, stp, fpa, dpa, o.brackt, o.ls[L_STMIN], o.ls[L_STMAX]);
+                if (mod) { fx = fx + stx * gtest; fy = fy + sty * gtest; gx = gx + gtest; gy = gy + gtest; }
                 if (o.brackt) {
                     if (fabs(sty - stx) >= 0.66 * o.ls[L_WIDTH1]) stp = stx + 0.5 * (sty - stx);
                     o.ls[L_WIDTH1] = o.ls[L_WIDTH];

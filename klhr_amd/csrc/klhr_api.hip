@@ -460,7 +460,9 @@ static int probe(klhr_sampler *s, int phase, const double *eta_or_t, int eta_col
     if (rc) return rc;
     rc = h2d(s, s->kp.d_eta, e4.data(), C * 4 * 8);
     if (rc) return rc;
-    rc = run_phases(s, phase, 1, 0, 0);
+    // KLHR_PROBE_REPEAT (diagnostics only): repeat the probe evaluation n times in one launch to time a bare evaluation
+    const char *rep = getenv("KLHR_PROBE_REPEAT");
+    rc = run_phases(s, phase, rep ? atoi(rep) : 1, 0, 0);
     if (rc) return rc;
     std::vector<double> dg(C * KLHR_NDIAG);
     rc = d2h(s, dg.data(), s->kp.d_diag, C * KLHR_NDIAG * 8);

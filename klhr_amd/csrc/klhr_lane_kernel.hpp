@@ -281,9 +281,19 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
         // =============================================================== fit
         if (p.phases & PH_FIT) {
             Opt o;
+            // fit() consumes exactly five normals — x0, then size-4 init of which the first two are discarded
+            // (klhr_sinh.py:184,191-193) — and nothing in between touches the generator, so all five are drawn here,
+            // with the whole wavefront converged, instead of inside the divergent stage-1 -> stage-2 transition.
+            double fit_n2 = 0, fit_n3 = 0;
             {
                 double x0v[4] = {0, 0, 0, 0};
-                if (active) x0v[0] = rng_std_normal(rng) * p.initscale;
+                if (active) {
+                    x0v[0] = rng_std_normal(rng) * p.initscale;
+                    (void)rng_std_normal(rng);
+                    (void)rng_std_normal(rng);
+                    fit_n2 = rng_std_normal(rng) * p.initscale;
+                    fit_n3 = rng_std_normal(rng) * p.initscale;
+                }
                 if (diag && active) dd[KLHR_D_X0] = x0v[0];
                 opt_begin(o, 1, x0v, 1e-5);
             }
@@ -309,13 +319,7 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
                             }
                             double s = o.H[0];
                             s = (s > 0 ? 1.0 : 0.0) * 0.5 * log(s);
-                            // init = rng.normal(size=4) * initscale, then [0], [1] overwritten (klhr_sinh.py:191-193):
-                            // four normals are consumed, the first two discarded (no loop: keeps init[] in registers)
-                            (void)rng_std_normal(rng);
-                            (void)rng_std_normal(rng);
-                            const double n2 = rng_std_normal(rng) * p.initscale;
-                            const double n3 = rng_std_normal(rng) * p.initscale;
-                            double init[4] = {o.xk[0], s, n2, n3};
+                            double init[4] = {o.xk[0], s, fit_n2, fit_n3};
                             if (diag) { dd[KLHR_D_INIT0] = init[0]; dd[KLHR_D_INIT1] = init[1]; dd[KLHR_D_INIT2] = init[2]; dd[KLHR_D_INIT3] = init[3]; }
                             opt_begin(o, 4, init, 1e-3);
                         } else {
