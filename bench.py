@@ -31,6 +31,13 @@ def algorithmic_bytes_per_iter(D, J=2):
     return 8 * ((5 + 2 * J) * D + J + (4 + J) * D) + 112
 
 
+def flop_equiv_per_iter(D):
+    """~14 KL evals x 8 nodes + ~8.5 single evals of (9D+10 flops + 1 transcendental) + ~40 flops and 3
+    transcendentals per node + ~11 BFGS updates of ~250 flops; a transcendental counted as 25 flops."""
+    node_evals = 14.0 * 8 + 8.5
+    return node_evals * (9 * D + 10 + 25) + 14.0 * 8 * (40 + 3 * 25) + 11 * 250
+
+
 def cpu_baseline(chains, warm, iters, threads):
     """The CPU oracle (oracle/klhr_oracle.c, a validated restatement of the reference path) timed on host cores."""
     os.environ["OMP_NUM_THREADS"] = str(threads)
@@ -134,9 +141,12 @@ def main():
                    "chains_per_gpu": C, "chains_total": C * world, "dim": D, "parallelism": f"chains sharded over {world} GPU(s), no collective"},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "klhr_iter_kernel", "algorithmic_bytes_per_chain_iter": b_iter,
+                     "kernel": s.kernel_name(), "algorithmic_bytes_per_chain_iter": b_iter,
                      "launch_ms": launch_s * 1e3, "launches": n_launch,
-                     "note": "the path is fp64-VALU/latency bound, not HBM bound (DESIGN.md §roofline)"},
+                     "fp64_valu": {"achieved_tflops": value / world * flop_equiv_per_iter(D) / 1e12, "peak_tflops": FP64_VALU_PEAK_TFLOPS,
+                                   "frac": value / world * flop_equiv_per_iter(D) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                                   "flop_equivalents_per_chain_iter": flop_equiv_per_iter(D)},
+                     "note": "the path is fp64-VALU/latency bound, not HBM bound (DESIGN.md section 6); fp64_valu counts algorithmic flop-equivalents (SURVEY section 8d)"},
     }
     if rank == 0:
         # grad-evals per iteration and acceptance (cheap state reads, outside the timed region)

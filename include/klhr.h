@@ -79,6 +79,9 @@ KLHR_API int klhr_abi_version(void);
 KLHR_API int klhr_dim(const klhr_sampler *s);                  /* replaces BSModel.dim() (bsmodel.py:39-40) */
 KLHR_API int klhr_chains(const klhr_sampler *s);
 KLHR_API int klhr_sync(klhr_sampler *s);                       /* wait for the handle's stream */
+/* which hot-path kernel this handle launches: 0 = octet-per-chain (klhr_iter_kernel), 1 = lane-per-chain
+ * (klhr_lane_kernel, model dimension <= 26).  Results are the same; only the mapping to the machine differs. */
+KLHR_API int klhr_kernel_variant(const klhr_sampler *s);
 
 /* ---- seeding / initialisation --------------------------------------------------------------- */
 /* replaces: MCMCBase.__init__ (mcmc.py:4-17: default_rng(seed), D normals consumed unless a theta

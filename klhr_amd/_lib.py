@@ -53,6 +53,7 @@ def lib():
         "klhr_dim": (C.c_int, [vp]),
         "klhr_chains": (C.c_int, [vp]),
         "klhr_sync": (C.c_int, [vp]),
+        "klhr_kernel_variant": (C.c_int, [vp]),
         "klhr_seed": (C.c_int, [vp, u64p, C.c_int]),
         "klhr_seed_state": (None, [C.c_uint64, u64p]),
         "klhr_window_closures": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, i64p, C.c_int]),
@@ -83,6 +84,7 @@ def lib():
 
 
 EXPORTS = ["klhr_create", "klhr_destroy", "klhr_last_error", "klhr_abi_version", "klhr_dim", "klhr_chains", "klhr_sync",
+           "klhr_kernel_variant",
            "klhr_seed", "klhr_seed_state", "klhr_window_closures", "klhr_step", "klhr_get_draws", "klhr_random_direction",
            "klhr_fit", "klhr_metropolis", "klhr_adapt", "klhr_kl_eval", "klhr_line_eval", "klhr_log_density_gradient",
            "klhr_primitives", "klhr_get_state", "klhr_set_state", "klhr_mh_seed", "klhr_mh_step", "klhr_pool_stats",
@@ -171,6 +173,9 @@ class Sampler:
 
     def sync(self):
         self._ck(self._L.klhr_sync(self._h), "klhr_sync")
+
+    def kernel_name(self):
+        return "klhr_lane_kernel" if self._L.klhr_kernel_variant(self._h) == 1 else "klhr_iter_kernel"
 
     def draws(self, first=0, n=None, total=None):
         n = int(n)

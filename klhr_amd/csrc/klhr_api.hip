@@ -118,6 +118,7 @@ extern "C" int klhr_abi_version(void) { return KLHR_ABI_VERSION; }
 extern "C" const char *klhr_last_error(const klhr_sampler *s) { return s ? s->err.c_str() : g_create_err.c_str(); }
 extern "C" int klhr_dim(const klhr_sampler *s) { return s ? s->D : KLHR_ERR_ARG; }
 extern "C" int klhr_chains(const klhr_sampler *s) { return s ? s->C : KLHR_ERR_ARG; }
+extern "C" int klhr_kernel_variant(const klhr_sampler *s) { return s ? (s->use_lane ? 1 : 0) : KLHR_ERR_ARG; }
 
 template <class T>
 static int dalloc(klhr_sampler *s, T **p, size_t n) {

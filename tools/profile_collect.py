@@ -1,0 +1,31 @@
+"""Copy the judged summaries of a tools/profile_round.sh run from gpurun_out/ into profiles/<tag>/ and refresh
+profiles/traffic.json (HBM bytes per launch of the hot kernel: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, KB units)."""
+import csv, glob, json, os, shutil, sys
+tag = sys.argv[1]
+key = sys.argv[2] if len(sys.argv) > 2 else "funnel-10-65536"
+iters_per_launch = int(sys.argv[3]) if len(sys.argv) > 3 else 50
+out = f"profiles/{tag}"
+os.makedirs(out, exist_ok=True)
+ks = max(glob.glob(f"gpurun_out/prof_{tag}_kt/*/*_kernel_stats.csv"), key=os.path.getmtime)
+shutil.copy(ks, f"{out}/kernel_stats.csv")
+rows = []
+vals = {}
+for name in ("fetch", "write"):
+    f = max(glob.glob(f"gpurun_out/prof_{tag}_{name}/*/*_counter_collection.csv"), key=os.path.getmtime)
+    for r in csv.DictReader(open(f)):
+        if "lane_kernel" in r["Kernel_Name"] or "iter_kernel" in r["Kernel_Name"]:
+            rows.append({k: r[k] for k in ("Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "VGPR_Count",
+                                           "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size", "Counter_Name", "Counter_Value")})
+            vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+w = csv.DictWriter(open(f"{out}/pmc_fetch_write.csv", "w"), fieldnames=list(rows[0].keys()))
+w.writeheader(); w.writerows(rows)
+# timed launches = the last 4 dispatches (200 steps / 50 per launch); draws are recorded only there
+fetch = sum(vals["FETCH_SIZE"][-4:]) / 4 * 1024 * 2
+write = sum(vals["WRITE_SIZE"][-4:]) / 4 * 1024
+tj_path = "profiles/traffic.json"
+tj = json.load(open(tj_path)) if os.path.exists(tj_path) else {}
+tj[key] = {"hbm_bytes_per_launch": fetch + write, "fetch_bytes_x2": fetch, "write_bytes": write, "iters_per_launch": iters_per_launch,
+           "source": f"profiles/{tag}/pmc_fetch_write.csv (mean of the 4 timed dispatches; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM)"}
+json.dump(tj, open(tj_path, "w"), indent=1)
+print(open(f"{out}/kernel_stats.csv").read())
+print(json.dumps(tj[key], indent=1))
