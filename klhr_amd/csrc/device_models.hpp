@@ -117,6 +117,76 @@ __device__ __forceinline__ void model_eval(const ModelData &md, XR xr, double cl
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Octet-cooperative evaluation of ONE point theta + t*rho: lane l8 of the chain's octet visits coordinates
+// i = l8, l8+8, ... and the partial sums are combined with the commutative butterfly `sum8` (all 8 lanes end with the
+// same bits).  Used by the octet kernel for the 1-D line objective and the MH step, where all 8 lanes would otherwise
+// repeat the same D-long loop.  Summation order differs from model_eval (strided partials), values agree to rounding.
+template <int MODEL, class SUM8>
+__device__ __forceinline__ void model_eval_split(const ModelData &md, const double2 *TR, double t, double cl, int l8, SUM8 sum8,
+                                                 double &logp, double &gdot) {
+    const int D = md.D;
+    if constexpr (MODEL == MODEL_FUNNEL) {
+        const double2 e0 = TR[0];
+        const double v = fma(t, e0.y, e0.x);
+        const double Da = (double)md.n;
+        const double ev = exp(-v);
+        double ss = 0.0, gd = 0.0;
+        for (int i = 1 + l8; i < D; i += 8) {
+            const double2 e = TR[i];
+            double xi = fma(t, e.y, e.x);
+            ss += xi * xi;
+            gd += clipc(-ev * xi, cl) * e.y;
+        }
+        ss = sum8(ss);
+        gd = sum8(gd);
+        double g0 = -v / 9.0 - 0.5 * Da + 0.5 * ev * ss;
+        gdot = clipc(g0, cl) * e0.y + gd;
+        logp = -v * v / 18.0 - 0.5 * Da * v - 0.5 * ev * ss;
+    } else if constexpr (MODEL == MODEL_ILL_NORMAL || MODEL == MODEL_NORMAL) {
+        double acc = 0.0, gd = 0.0;
+        for (int i = l8; i < D; i += 8) {
+            const double2 e = TR[i];
+            double xi = fma(t, e.y, e.x);
+            double gi;
+            if constexpr (MODEL == MODEL_ILL_NORMAL) { double is = md.aux[i]; double z = xi * is; acc += z * z; gi = -z * is; }
+            else { acc += xi * xi; gi = -xi; }
+            gd += clipc(gi, cl) * e.y;
+        }
+        gdot = sum8(gd);
+        logp = -0.5 * sum8(acc);
+    } else {   // MODEL_GLMM_POISSON
+        const int n = md.n;
+        const double *x1 = md.aux, *x2 = md.aux + n, *x3 = md.aux + 2 * n, *Cn = md.aux + 3 * n;
+        const double2 ea = TR[0], eb0 = TR[1], eb1 = TR[2], eb2 = TR[3], el = TR[4];
+        const double alpha = fma(t, ea.y, ea.x), b0 = fma(t, eb0.y, eb0.x), b1 = fma(t, eb1.y, eb1.x), b2 = fma(t, eb2.y, eb2.x);
+        const double ell = fma(t, el.y, el.x), sigma = exp(ell);
+        double sr = 0, s1 = 0, s2 = 0, s3 = 0, sre = 0, see = 0, lik = 0, gd = 0;
+        for (int i = l8; i < n; i += 8) {
+            const double2 e2 = TR[5 + i];
+            double e = fma(t, e2.y, e2.x);
+            double eta = alpha + x1[i] * b0 + x2[i] * b1 + x3[i] * b2 + sigma * e;
+            double mu = exp(eta);
+            double r = Cn[i] - mu;
+            lik += Cn[i] * eta - mu;
+            see += e * e;
+            sr += r; s1 += x1[i] * r; s2 += x2[i] * r; s3 += x3[i] * r;
+            sre += r * e;
+            gd += clipc(-e + sigma * r, cl) * e2.y;
+        }
+        sr = sum8(sr); s1 = sum8(s1); s2 = sum8(s2); s3 = sum8(s3); sre = sum8(sre); see = sum8(see); lik = sum8(lik); gd = sum8(gd);
+        double lp = -alpha * alpha / 50.0;
+        lp -= b0 * b0 / 50.0; lp -= b1 * b1 / 50.0; lp -= b2 * b2 / 50.0;
+        lp -= 0.5 * ell * ell;
+        lp += -0.5 * see + lik;
+        double g0 = -alpha / 25.0 + sr, g1 = -b0 / 25.0 + s1, g2 = -b1 / 25.0 + s2, g3 = -b2 / 25.0 + s3, g4 = -ell + sigma * sre;
+        gd += clipc(g0, cl) * ea.y; gd += clipc(g1, cl) * eb0.y; gd += clipc(g2, cl) * eb1.y; gd += clipc(g3, cl) * eb2.y;
+        gd += clipc(g4, cl) * el.y;
+        gdot = gd;
+        logp = lp;
+    }
+}
+
 }  // namespace klhr
 
 // ---------------------------------------------------------------------------------------------------------------

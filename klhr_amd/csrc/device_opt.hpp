@@ -69,7 +69,9 @@ __device__ __forceinline__ void opt_request(Opt &o, double a) {
 }
 
 // _dcsrch.py:502-728
-// (force-inlined at its single call site: by-reference arguments of an out-of-line copy would live in scratch memory)
+// The body is force-inlined into two wrappers (below): dcstep_inl for the lane-per-chain kernel, which runs alone on
+// its SIMD and can afford the registers, and the out-of-line dcstep_call for the octet kernel, where an inlined copy
+// costs a wavefront of occupancy (its by-reference state then round-trips through scratch memory, 8 doubles per call).
 __device__ __forceinline__ void dcstep(double &stx, double &fx, double &dx, double &sty, double &fy, double &dy, double &stp,
                                        double fp, double dp, bool &brackt, double stpmin, double stpmax) {
     const double sgnd = npsign(dp) * npsign(dx);
@@ -140,8 +142,15 @@ __device__ __forceinline__ void dcstep(double &stx, double &fx, double &dx, doub
     stp = stpf;
 }
 
+#ifndef KLHR_HOST_HARNESS
+__device__ __attribute__((noinline)) void dcstep_call(double &stx, double &fx, double &dx, double &sty, double &fy, double &dy,
+                                                      double &stp, double fp, double dp, bool &brackt, double stpmin, double stpmax) {
+    dcstep(stx, fx, dx, sty, fy, dy, stp, fp, dp, brackt, stpmin, stpmax);
+}
+#endif
+
 // _linesearch.py:503-549 — "None" (errstate raise / non-finite) is returned as false
-__device__ __forceinline__ bool cubicmin(double a, double fa, double fpa, double b, double fb, double c, double fc, double &xmin) {
+__device__ inline bool cubicmin(double a, double fa, double fpa, double b, double fb, double c, double fc, double &xmin) {
     double C = fpa, db = b - a, dc = c - a;
     double denom = (db * dc) * (db * dc) * (db - dc);
     double d00 = dc * dc, d01 = -(db * db), d10 = -(dc * dc * dc), d11 = db * db * db;
@@ -156,7 +165,7 @@ __device__ __forceinline__ bool cubicmin(double a, double fa, double fpa, double
     xmin = x;
     return true;
 }
-__device__ __forceinline__ bool quadmin(double a, double fa, double fpa, double b, double fb, double &xmin) {
+__device__ inline bool quadmin(double a, double fa, double fpa, double b, double fb, double &xmin) {
     double D = fa, C = fpa, db = b - a * 1.0;
     if (db * db == 0.0) return false;
     double B = (fb - D - C * db) / (db * db);
@@ -210,6 +219,8 @@ __device__ __forceinline__ void opt_cache_store(Opt &o, double f, const double *
 }
 
 // Consume the objective value f and gradient g at o.xt; leave either the next request in o.xt or pc == PC_DONE.
+// OUTLINE selects the out-of-line dcstep (octet kernel); the arithmetic is identical.
+template <bool OUTLINE = false>
 __device__ inline void opt_advance(Opt &o, double f, const double *g) {
     const double c1 = 1e-4, c2 = 0.9, stpmin = 1e-100, stpmax = 1e100, xtol = 1e-14;
     const double phi0 = o.old_fval;
@@ -254,7 +265,11 @@ __device__ inline void opt_advance(Opt &o, double f, const double *g) {
                     fpa = f - stp * gtest; fx = fx - stx * gtest; fy = fy - sty * gtest;
                     dpa = dphi - gtest; gx = gx - gtest; gy = gy - gtest;
                 }
-                dcstep(stx, fx, gx, sty, fy, gy, stp, fpa, dpa, o.brackt, o.ls[L_STMIN], o.ls[L_STMAX]);
+#ifndef KLHR_HOST_HARNESS
+                if constexpr (OUTLINE) dcstep_call(stx, fx, gx, sty, fy, gy, stp, fpa, dpa, o.brackt, o.ls[L_STMIN], o.ls[L_STMAX]);
+                else
+#endif
+                    dcstep(stx, fx, gx, sty, fy, gy, stp, fpa, dpa, o.brackt, o.ls[L_STMIN], o.ls[L_STMAX]);
                 if (mod) { fx = fx + stx * gtest; fy = fy + sty * gtest; gx = gx + gtest; gy = gy + gtest; }
                 if (o.brackt) {
                     if (fabs(sty - stx) >= 0.66 * o.ls[L_WIDTH1]) stp = stx + 0.5 * (sty - stx);

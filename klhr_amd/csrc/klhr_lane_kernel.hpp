@@ -154,23 +154,6 @@ __device__ inline void lane_close_window(const KParams &p, long long c, long lon
 #define KLHR_NVG 4
 #endif
 
-// log(cosh(a)) from m = exp(-|a|) (already available as min(E, 1/E)):
-//     log cosh a = |a| - ln 2 + log1p(m^2),   log1p(u) = 2 atanh(u / (2 + u)),  u in (0, 1]  =>  s = u/(2+u) <= 1/3
-// atanh by its odd series to s^35 (truncation < 2e-18).  Absolute error <= ~2e-16, no worse than log() applied to a
-// rounded cosh, at ~40 instead of ~100 instructions.
-__device__ __forceinline__ double log_cosh_from_exp(double absa, double m) {
-    const double u = m * m;
-    const double s = u / (2.0 + u);
-    const double z = s * s;
-    double q = 1.0 / 35.0;
-    q = fma(q, z, 1.0 / 33.0); q = fma(q, z, 1.0 / 31.0); q = fma(q, z, 1.0 / 29.0); q = fma(q, z, 1.0 / 27.0);
-    q = fma(q, z, 1.0 / 25.0); q = fma(q, z, 1.0 / 23.0); q = fma(q, z, 1.0 / 21.0); q = fma(q, z, 1.0 / 19.0);
-    q = fma(q, z, 1.0 / 17.0); q = fma(q, z, 1.0 / 15.0); q = fma(q, z, 1.0 / 13.0); q = fma(q, z, 1.0 / 11.0);
-    q = fma(q, z, 1.0 / 9.0);  q = fma(q, z, 1.0 / 7.0);  q = fma(q, z, 1.0 / 5.0);  q = fma(q, z, 1.0 / 3.0);
-    q = fma(q, z, 1.0);
-    const double lp = 2.0 * s * q;                       // log1p(u) in [0, ln 2]
-    return absa + (lp - 0.6931471805599453094);
-}
 template <int MODEL>
 __device__ __forceinline__ void lane_eval_kl(const KParams &p, const double2 *TR, const double *xt, double &f, double *g) {
     constexpr int NVG = KLHR_NVG;
