@@ -88,7 +88,11 @@ def main():
     else:
         data, D = np.array([float(args.dim)]), args.dim
     C = args.chains
-    s = _lib.Sampler(_lib.MODEL_IDS[args.model], data, C, device=local_rank, warmup=100)   # experiment_funnel.py:21 default
+    ndev = _lib.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py: no HIP device visible (there is no CPU fallback)")
+    device = local_rank % ndev      # one rank per GPU on the 8-GPU node; rehearsals on a 1-GPU box share device 0
+    s = _lib.Sampler(_lib.MODEL_IDS[args.model], data, C, device=device, warmup=100)   # experiment_funnel.py:21 default
     seeds = np.uint64(args.seed) + np.uint64(rank) * np.uint64(C) + np.arange(C, dtype=np.uint64)
     s.seed(seeds)
 

@@ -76,6 +76,7 @@ KLHR_API int klhr_create(const klhr_config *cfg, const double *model_data, size_
 KLHR_API void klhr_destroy(klhr_sampler *s);
 KLHR_API const char *klhr_last_error(const klhr_sampler *s);   /* s may be NULL: last create() error */
 KLHR_API int klhr_abi_version(void);
+KLHR_API int klhr_device_count(void);                          /* visible HIP devices (0 when none / no driver) */
 KLHR_API int klhr_dim(const klhr_sampler *s);                  /* replaces BSModel.dim() (bsmodel.py:39-40) */
 KLHR_API int klhr_chains(const klhr_sampler *s);
 KLHR_API int klhr_sync(klhr_sampler *s);                       /* wait for the handle's stream */

@@ -50,6 +50,7 @@ def lib():
         "klhr_destroy": (None, [vp]),
         "klhr_last_error": (C.c_char_p, [vp]),
         "klhr_abi_version": (C.c_int, []),
+        "klhr_device_count": (C.c_int, []),
         "klhr_dim": (C.c_int, [vp]),
         "klhr_chains": (C.c_int, [vp]),
         "klhr_sync": (C.c_int, [vp]),
@@ -83,12 +84,16 @@ def lib():
     return L
 
 
-EXPORTS = ["klhr_create", "klhr_destroy", "klhr_last_error", "klhr_abi_version", "klhr_dim", "klhr_chains", "klhr_sync",
+EXPORTS = ["klhr_create", "klhr_destroy", "klhr_last_error", "klhr_abi_version", "klhr_device_count", "klhr_dim", "klhr_chains", "klhr_sync",
            "klhr_kernel_variant",
            "klhr_seed", "klhr_seed_state", "klhr_window_closures", "klhr_step", "klhr_get_draws", "klhr_random_direction",
            "klhr_fit", "klhr_metropolis", "klhr_adapt", "klhr_kl_eval", "klhr_line_eval", "klhr_log_density_gradient",
            "klhr_primitives", "klhr_get_state", "klhr_set_state", "klhr_mh_seed", "klhr_mh_step", "klhr_pool_stats",
            "klhr_pool_apply", "klhr_last_step_timing"]
+
+
+def device_count():
+    return lib().klhr_device_count()
 
 
 def dptr(a):

@@ -115,6 +115,10 @@ extern "C" int klhr_window_closures(int64_t warmup, int64_t windowsize, int64_t 
 }
 
 extern "C" int klhr_abi_version(void) { return KLHR_ABI_VERSION; }
+extern "C" int klhr_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
 extern "C" const char *klhr_last_error(const klhr_sampler *s) { return s ? s->err.c_str() : g_create_err.c_str(); }
 extern "C" int klhr_dim(const klhr_sampler *s) { return s ? s->D : KLHR_ERR_ARG; }
 extern "C" int klhr_chains(const klhr_sampler *s) { return s ? s->C : KLHR_ERR_ARG; }
