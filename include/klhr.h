@@ -55,13 +55,15 @@ typedef struct klhr_config {
     int32_t model_id;          /* enum klhr_model */
     int32_t chains;            /* C: number of independent chains (extension; reference = 1) */
     int32_t N;                 /* quadrature nodes; this build supports N == 8 (one lane per node) */
-    int32_t K;                 /* over-relaxation K (kept for API parity; unused when overrelaxed == 0) */
+    int32_t K;                 /* over-relaxation K (klhr_sinh.py:216); used when overrelaxed != 0 */
     int32_t J;                 /* online-PCA eigenvectors; J <= 3 */
     int32_t max_init_tries;
     double l;                  /* CCIPCA amnesia */
     double initscale, tol, grad_clip, scale_clip;
     int64_t warmup, windowsize, windowscale;
-    int32_t scale_dir_cov, overrelaxed, eigen_method_one;
+    int32_t scale_dir_cov, overrelaxed, eigen_method_one;   /* overrelaxed: binomial/beta variates come from the
+                                                              * chain's own PCG64 stream (the reference uses SciPy's unseeded
+                                                              * global RNG there: distribution-exact, not stream-exact) */
     int32_t reserved;
     const double *quad_x;      /* N probabilists' Gauss-Hermite nodes   (klhr_sinh.py:44-47) */
     const double *quad_w;      /* N weights                                                  */

@@ -171,7 +171,7 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
     if (!cfg || !out || cfg->struct_size != sizeof(klhr_config)) return fail("klhr_create: bad config struct");
     if (cfg->N != 8) return fail("klhr_create: this build maps one lane per quadrature node and supports N == 8 only");
     if (cfg->J < 1 || cfg->J > 3) return fail("klhr_create: need 1 <= J <= 3");
-    if (cfg->overrelaxed) return fail("klhr_create: overrelaxed=True is not implemented (reference uses SciPy's unseeded global RNG)");
+    if (cfg->overrelaxed && (cfg->K < 1 || cfg->K > 64)) return fail("klhr_create: overrelaxed needs 1 <= K <= 64");
     if (cfg->chains < 1) return fail("klhr_create: chains < 1");
     if (!model_data || n_model_data < 1 || !cfg->quad_x || !cfg->quad_w || !cfg->quad_asinh_x) return fail("klhr_create: null data");
     int D = 0, n = 0;
@@ -228,7 +228,9 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
     KParams &k = s->kp;
     const size_t C = s->C, nc = s->ncol, J = cfg->J;
     k.C = s->C; k.D = D; k.S = S; k.ncol = s->ncol; k.J = cfg->J;
-    k.flags = (cfg->scale_dir_cov ? FLAG_SCALE_DIR_COV : 0) | (cfg->eigen_method_one ? FLAG_EIGEN_ONE : 0);
+    k.flags = (cfg->scale_dir_cov ? FLAG_SCALE_DIR_COV : 0) | (cfg->eigen_method_one ? FLAG_EIGEN_ONE : 0) |
+              (cfg->overrelaxed ? FLAG_OVERRELAXED : 0);
+    k.K = cfg->K;
     k.tol = cfg->tol; k.scale_clip = cfg->scale_clip; k.initscale = cfg->initscale; k.l = cfg->l;
     for (int i = 0; i < 8; i++) { k.wq[i] = cfg->quad_w[i]; k.asx[i] = cfg->quad_asinh_x[i]; }
     TRY(dalloc(s, &s->d_aux, aux.size()));

@@ -34,10 +34,10 @@
 namespace klhr {
 
 enum { PH_DIR = 1, PH_FIT = 2, PH_MH = 4, PH_ADAPT = 8, PH_ALL = 15, PH_KL = 16, PH_LINE = 32 };
-enum { FLAG_SCALE_DIR_COV = 1, FLAG_EIGEN_ONE = 2, FLAG_DIAG = 4, FLAG_DRAWS = 8 };
+enum { FLAG_SCALE_DIR_COV = 1, FLAG_EIGEN_ONE = 2, FLAG_DIAG = 4, FLAG_DRAWS = 8, FLAG_OVERRELAXED = 16 };
 
 struct KParams {
-    int C, D, S, ncol, J, flags, phases, n_iters;
+    int C, D, S, ncol, J, K, flags, phases, n_iters;
     ModelData md;
     double tol, scale_clip, initscale, l;
     double wq[8], asx[8];      // quadrature weights and asinh(node) (nodes themselves are not needed on the device)
@@ -109,6 +109,31 @@ __device__ inline double sa_log_q(double x, const double *eta, double tol, doubl
 // One objective evaluation for one chain, spread over its octet.
 //   n == 4: KL(eta = xt) value and gradient (klhr_sinh.py:163-176): lane j evaluates node j
 //   n == 1: (-logp, -grad.rho) at theta + xt[0]*rho (klhr_sinh.py:178-180), computed redundantly by the octet
+// Over-relaxed proposal (klhr_sinh.py:215-228, Neal's ordered over-relaxation on the fitted proposal's CDF):
+//   u = Phi(T_inv(0)); r ~ Binomial(K, u); r > K-r: u' = u * Beta(K-r+1, 2r-K); r < K-r: u' = 1 - (1-u) * Beta(r+1, K-2r);
+//   r == K-r: u' = u; z' = T(Phi^-1(u')).
+// The reference draws r and the Beta variate from SciPy's *global, unseeded* generator, so its stream cannot be matched;
+// here they come from the chain's own PCG64 stream with a fixed consumption (documented in DESIGN.md §2, row a13):
+//   K uniforms for the binomial (count of U_k < u), then a + b uniforms for Beta(a, b) = Ga / (Ga + Gb) with
+//   Ga = -sum log(1 - U_i) over a uniforms (integer-shape gamma).  Distributions are exactly those of scipy.stats.
+__device__ inline double overrelaxed_zp(Pcg64 &rng, const double *eta, int K, double tol, double sc) {
+    const double u = normcdf(sa_T_inv(0.0, eta, tol, sc));
+    int r = 0;
+    for (int k = 0; k < K; k++) r += (pcg_next_double(rng) < u) ? 1 : 0;
+    double up = u;
+    int a = 0, b = 0;
+    if (r > K - r) { a = K - r + 1; b = 2 * r - K; }
+    else if (r < K - r) { a = r + 1; b = K - 2 * r; }
+    if (a > 0) {
+        double ga = 0.0, gb = 0.0;
+        for (int i = 0; i < a; i++) ga -= log(1.0 - pcg_next_double(rng));
+        for (int i = 0; i < b; i++) gb -= log(1.0 - pcg_next_double(rng));
+        const double v = ga / (ga + gb);
+        up = (r > K - r) ? u * v : 1.0 - (1.0 - u) * v;
+    }
+    return sa_T(normcdfinv(up), eta, tol, sc);
+}
+
 // log(cosh(a)) from m = exp(-|a|): |a| - ln 2 + log1p(m^2), log1p(u) = 2 atanh(u/(2+u)) by its odd series (s <= 1/3,
 // truncation < 2e-18).  Absolute error ~2e-16, at ~40 instead of ~100 instructions for log(cosh(.)).
 __device__ __forceinline__ double log_cosh_from_exp(double absa, double m) {
@@ -462,8 +487,8 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
         // =============================================================== MH step (klhr_sinh.py:242-260)
         if (p.phases & PH_MH) {
             draw += 1;
-            const double z = rng_std_normal(rng);
-            const double zp = sa_T(z, eta, p.tol, p.scale_clip);
+            const double zp = (p.flags & FLAG_OVERRELAXED) ? overrelaxed_zp(rng, eta, p.K, p.tol, p.scale_clip)
+                                                           : sa_T(rng_std_normal(rng), eta, p.tol, p.scale_clip);
             double logp, gdot;
             const double t = (l8 == 0) ? zp : 0.0;
             model_eval<MODEL>(p.md, [&](int i, double &xi, double &ri) { double2 v = TR[i]; ri = v.y; xi = fma(t, v.y, v.x); },

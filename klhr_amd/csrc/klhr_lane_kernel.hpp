@@ -337,8 +337,8 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
         // =============================================================== MH step
         if ((p.phases & PH_MH) && active) {
             draw += 1;
-            const double z = rng_std_normal(rng);
-            const double zp = sa_T(z, eta, p.tol, p.scale_clip);
+            const double zp = (p.flags & FLAG_OVERRELAXED) ? overrelaxed_zp(rng, eta, p.K, p.tol, p.scale_clip)
+                                                           : sa_T(rng_std_normal(rng), eta, p.tol, p.scale_clip);
             double t2[2] = {zp, 0.0}, lp2[2], gd2[2];
             model_eval_nv<MODEL, 2>(p.md, TR, t2, INFINITY, lp2, gd2);
             double r = lp2[0];

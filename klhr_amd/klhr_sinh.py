@@ -10,8 +10,9 @@ Same constructor keywords, attributes and methods as the reference class; the wo
     _random_direction()       klhr_random_direction     klhr_sinh.py:203-213
     _metropolis_step(eta,rho) klhr_metropolis           klhr_sinh.py:242-260
     _T/_T_inv/_log_q/...      klhr_primitives           klhr_sinh.py:112-156,230-240
-`overrelaxed=True` (the reference's constructor default, but not what its experiment CLIs pass) draws from SciPy's
-unseeded global RNG in the reference and is not implemented here: pass overrelaxed=False.
+`overrelaxed=True` (the reference's constructor default; its experiment CLIs pass False unless -o) is supported: the
+reference draws the binomial/beta variates of the over-relaxed proposal from SciPy's unseeded global RNG, here they
+come from the chain's own PCG64 stream (same distributions, documented consumption; parity is statistical).
 """
 import numpy as np
 
@@ -25,9 +26,6 @@ class KLHRSINH(MCMCBase):
                  windowscale=2, tol=1e-10, grad_clip=1e15, scale_clip=300, scale_dir_cov=False, overrelaxed=True,
                  eigen_method_one=False, max_init_tries=100, chains=None, device=None):
         super().__init__(bsmodel, -1, theta=theta, seed=seed, chains=chains, device=device)
-        if overrelaxed:
-            raise NotImplementedError("overrelaxed=True is not available on the GPU path (the reference's over-relaxed "
-                                      "proposal uses SciPy's unseeded global RNG); construct with overrelaxed=False")
         self.N, self.K, self.J, self.l = N, K, J, l
         self._tol, self._grad_clip, self._scale_clip = tol, grad_clip, scale_clip
         self._max_init_tries, self._initscale = max_init_tries, initscale
@@ -36,7 +34,7 @@ class KLHRSINH(MCMCBase):
         self._sampler = _lib.Sampler(bsmodel.model_id, bsmodel.model_data, self._C, device=self._device, N=N, K=K, J=J, l=l,
                                      initscale=initscale, warmup=warmup, windowsize=windowsize, windowscale=windowscale,
                                      tol=tol, grad_clip=grad_clip, scale_clip=scale_clip, scale_dir_cov=scale_dir_cov,
-                                     overrelaxed=False, eigen_method_one=eigen_method_one, max_init_tries=max_init_tries)
+                                     overrelaxed=overrelaxed, eigen_method_one=eigen_method_one, max_init_tries=max_init_tries)
         self.x, self.w = self._sampler.x.copy(), self._sampler.w.copy()
         self._sampler.seed(self._seeds, theta_given=self._theta_given)     # MCMCBase.__init__ + _initialize, on device
 

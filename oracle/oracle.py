@@ -61,6 +61,10 @@ def lib():
         L.klhr_oracle_primitives_inv.argtypes = [vp, C.c_double, dp, dp]
         L.klhr_oracle_get.argtypes = [vp, C.c_int, vp]
         L.klhr_oracle_set.argtypes = [vp, C.c_int, vp]
+        L.klhr_oracle_ndtr.argtypes = [C.c_double]
+        L.klhr_oracle_ndtr.restype = C.c_double
+        L.klhr_oracle_ndtri.argtypes = [C.c_double]
+        L.klhr_oracle_ndtri.restype = C.c_double
         L.klhr_oracle_seed_state.argtypes = [C.c_uint64, u64p]
         L.klhr_oracle_rng_raw.argtypes = [u64p, C.c_long, u64p]
         L.klhr_oracle_rng_double.argtypes = [u64p, C.c_long, dp]
@@ -104,7 +108,8 @@ def model_data(stem, data):
 
 
 class Chain:
-    """One KLHRSINH chain (constructor defaults of klhr_sinh.py:15-32, except overrelaxed which must be False)."""
+    """One KLHRSINH chain (constructor defaults of klhr_sinh.py:15-32, except overrelaxed which defaults to False:
+    the over-relaxed variates use this build's own RNG convention, see klhr_oracle.c: overrelaxed_zp)."""
 
     def __init__(self, stem, data, seed=None, N=8, K=10, J=2, l=4, initscale=0.1, warmup=1000, windowsize=50,
                  windowscale=2, tol=1e-10, grad_clip=1e15, scale_clip=300, scale_dir_cov=False, overrelaxed=False,

@@ -414,10 +414,23 @@ def g9_mh():
     np.savez(os.path.join(HERE, "g9_mh.npz"), **out)
 
 
+def g10_overrelaxed():
+    """Samples of the reference's over-relaxed proposal z' (klhr_sinh.py:215-228).  It draws from SciPy's global legacy
+    generator, seeded here with np.random.seed so the fixture is reproducible; only the DISTRIBUTION can be compared."""
+    a = ref_klhr_sinh.KLHRSINH(make_model("normal2"), seed=0, overrelaxed=True)
+    etas = np.array([[0.3, 0.2, -0.1, 0.25], [-1.0, 1.1, 0.3, -0.6], [0.0, 0.0, 0.0, 0.0]])
+    out = {"etas": etas, "K": np.array([a.K])}
+    np.random.seed(20261004)
+    for i, eta in enumerate(etas):
+        out[f"zp{i}"] = np.array([float(np.asarray(a._overrelaxed_proposal(eta)).reshape(-1)[0]) for _ in range(4000)])
+        out[f"u{i}"] = np.array([float(np.asarray(a._CDF(np.zeros(1), eta)).reshape(-1)[0])])
+    np.savez(os.path.join(HERE, "g10_overrelaxed.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g7", "g8", "g8p", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g7", "g8", "g8p", "g9", "g10"]
     fns = {"g1": g1_quadrature, "g2": g2_rng, "g3": g3_primitives, "g4": g4_kl, "g7": g7_online,
-           "g8": g8_chains, "g8p": g8_untouched, "g9": g9_mh}
+           "g8": g8_chains, "g8p": g8_untouched, "g9": g9_mh, "g10": g10_overrelaxed}
     for w in which:
         print("==", w, flush=True)
         fns[w]()

@@ -99,10 +99,14 @@ def test_pieces_with_reference_method_names(oracle):
     assert algo._grad_T(0.0, eta).shape == (4,)
 
 
-def test_overrelaxed_default_fails_loudly():
-    from klhr_amd import KLHRSINH
-    with pytest.raises(NotImplementedError):
-        KLHRSINH(funnel_model(), seed=0)
+def test_reference_constructor_defaults_work():
+    """KLHRSINH(model) with the reference's constructor defaults (overrelaxed=True, warmup=1000: klhr_sinh.py:15-32)."""
+    from klhr_amd import BSModel, KLHRSINH
+    m = BSModel(os.path.join(STAN, "normal.stan"), os.path.join(STAN, "normal.json"))
+    algo = KLHRSINH(m, seed=4, chains=512)
+    dr = algo.draws(1500)[300:].reshape(-1, 2)
+    assert np.abs(dr.mean(axis=0)).max() < 0.05 and np.abs(dr.var(axis=0) - 1).max() < 0.06
+    assert 0.5 < algo.acceptance_probability.mean() <= 1.0
 
 
 def test_mh_class_vs_golden():

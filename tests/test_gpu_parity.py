@@ -264,3 +264,37 @@ def test_mh_sampler_vs_golden(name):
         assert np.allclose(mine, ref, rtol=0, atol=1e-12)
         assert np.array_equal(s.get("rng")[k], g[f"{name}_s{k}_state1"])
         assert abs(s.get("acc")[k] - g[f"{name}_s{k}_acc"][0]) < 1e-12
+
+
+def test_overrelaxed_proposal_vs_oracle(oracle):
+    """a13: the over-relaxed MH step.  GPU and oracle share the RNG convention (K uniforms, then a + b uniforms), so the
+    stream position is exact and z' agrees to the accuracy of Phi / Phi^-1 (ocml vs the oracle's erfc-based versions)."""
+    g = golden("g8_funnel10_s0_w100.npz")
+    M = 256
+    stem, data = model_spec("funnel10")
+    s = make_sampler(stem, data, M, warmup=100, overrelaxed=True)
+    s.set("theta", g["theta_before"][:M])
+    s.set("rng", g["state_before"][:M])
+    cnt = np.zeros((M, 4), dtype=np.int64)
+    cnt[:, 0] = np.arange(M)
+    s.set("counters", cnt)
+    s.metropolis(g["eta"][:M], g["rho"][:M])
+    d = s.get("diag")
+    from klhr_amd._lib import DIAG_COLS as DC
+    col = {k: i for i, k in enumerate(DC)}
+    th = s.get("theta")
+    rng = s.get("rng")
+    n_atom = 0
+    for m in range(M):
+        o = oracle.Chain(stem, data, seed=0, warmup=100, overrelaxed=True)
+        o.set("theta", g["theta_before"][m]); o.set("rng", g["state_before"][m]); o.set("draw", m)
+        o.metropolis(g["eta"][m], g["rho"][m])
+        od = o.get("diag")
+        assert np.array_equal(o.get("rng"), rng[m]), m
+        assert abs(d[m, col["zp"]] - od["zp"]) <= 1e-9 * (1 + abs(od["zp"])), (m, d[m, col["zp"]], od["zp"])
+        assert d[m, col["logu"]] == pytest.approx(od["logu"], rel=1e-15)
+        if abs(od["logu"] - min(0.0, od["r"])) > 1e-6:
+            assert d[m, col["accept"]] == od["accept"]
+            assert np.allclose(th[m], o.get("theta"), rtol=1e-9, atol=1e-10)
+        n_atom += abs(od["zp"]) < 1e-9
+    assert 0 < n_atom < M          # both the u' = u branch and the beta branches were exercised

@@ -57,7 +57,7 @@ def test_compute_fails_loudly_without_gpu(lib):
 
 
 def test_create_rejects_unsupported_configs(lib):
-    for kw in (dict(N=4), dict(J=5), dict(overrelaxed=True)):
+    for kw in (dict(N=4), dict(J=5), dict(overrelaxed=True, K=0)):
         with pytest.raises(lib.KlhrError):
             lib.Sampler(lib.MODEL_IDS["funnel"], np.array([9.0]), 8, **kw)
 
