@@ -161,6 +161,13 @@ KLHR_API int klhr_mh_step(klhr_sampler *s, double stepsize, int64_t n_iters, int
 KLHR_API int klhr_pool_stats(klhr_sampler *s, double *out, size_t n_out);
 /* Overwrite every chain's direction mean/cov with pooled values (D each) at a closure.            */
 KLHR_API int klhr_pool_apply(klhr_sampler *s, const double *mean, const double *cov);
+/* Full-covariance variant: sufficient statistics of the draws recorded by the last recording call,
+ * iterations [first_iter, first_iter + n_iters): out = [count, sum theta (D), sum theta theta^T (D x D, row major)],
+ * computed as one fp64 MFMA Gram product over the (n_iters*C) x D draws matrix (v_mfma_f64_16x16x4_f64).           */
+KLHR_API int klhr_pool_gram(klhr_sampler *s, int64_t first_iter, int64_t n_iters, double *out, size_t n_out);
+/* ... and the matching setter: pooled mean (D), diagonal of the pooled covariance (D), unit eigenvectors (D x ncol,
+ * row major, ncol = J or J + 1 with eigen_method_one) and eigenvalues (ncol) for every chain.                         */
+KLHR_API int klhr_pool_apply_full(klhr_sampler *s, const double *mean, const double *cov_diag, const double *eigvecs, const double *eigvals);
 
 /* ---- timing ---------------------------------------------------------------------------------- */
 /* HIP-event time (ms) of the kernels launched by the most recent klhr_step on the handle's stream,

@@ -74,6 +74,8 @@ def lib():
         "klhr_mh_step": (C.c_int, [vp, C.c_double, C.c_int64, C.c_int]),
         "klhr_pool_stats": (C.c_int, [vp, dp, C.c_size_t]),
         "klhr_pool_apply": (C.c_int, [vp, dp, dp]),
+        "klhr_pool_gram": (C.c_int, [vp, C.c_int64, C.c_int64, dp, C.c_size_t]),
+        "klhr_pool_apply_full": (C.c_int, [vp, dp, dp, dp, dp]),
         "klhr_last_step_timing": (C.c_int, [vp, dp, C.POINTER(C.c_int)]),
     }
     for name, (res, args) in sig.items():
@@ -89,7 +91,7 @@ EXPORTS = ["klhr_create", "klhr_destroy", "klhr_last_error", "klhr_abi_version",
            "klhr_seed", "klhr_seed_state", "klhr_window_closures", "klhr_step", "klhr_get_draws", "klhr_random_direction",
            "klhr_fit", "klhr_metropolis", "klhr_adapt", "klhr_kl_eval", "klhr_line_eval", "klhr_log_density_gradient",
            "klhr_primitives", "klhr_get_state", "klhr_set_state", "klhr_mh_seed", "klhr_mh_step", "klhr_pool_stats",
-           "klhr_pool_apply", "klhr_last_step_timing"]
+           "klhr_pool_apply", "klhr_pool_gram", "klhr_pool_apply_full", "klhr_last_step_timing"]
 
 
 def device_count():
@@ -287,3 +289,14 @@ class Sampler:
         mean = np.ascontiguousarray(mean, dtype=np.float64)
         cov = np.ascontiguousarray(cov, dtype=np.float64)
         self._ck(self._L.klhr_pool_apply(self._h, dptr(mean), dptr(cov)), "klhr_pool_apply")
+
+    def pool_gram(self, first, n):
+        """[count, sum theta (D), sum theta theta^T (D, D)] over recorded draws [first, first + n) — fp64 MFMA Gram kernel."""
+        out = np.empty(1 + self.D + self.D * self.D)
+        self._ck(self._L.klhr_pool_gram(self._h, int(first), int(n), dptr(out), out.size), "klhr_pool_gram")
+        return out
+
+    def pool_apply_full(self, mean, cov_diag, eigvecs, eigvals):
+        a = [np.ascontiguousarray(x, dtype=np.float64) for x in (mean, cov_diag, eigvecs, eigvals)]
+        assert a[2].shape == (self.D, self.ncol) and a[3].shape == (self.ncol,)
+        self._ck(self._L.klhr_pool_apply_full(self._h, dptr(a[0]), dptr(a[1]), dptr(a[2]), dptr(a[3])), "klhr_pool_apply_full")

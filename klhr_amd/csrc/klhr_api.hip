@@ -663,3 +663,64 @@ extern "C" int klhr_pool_apply(klhr_sampler *s, const double *mean, const double
     (void)hipFree(d_m);
     return rc;
 }
+
+extern "C" int klhr_pool_gram(klhr_sampler *s, int64_t first_iter, int64_t n_iters, double *out, size_t n_out) {
+    if (!s || !out || first_iter < 0 || n_iters < 1 || first_iter + n_iters > s->draws_iters) return KLHR_ERR_ARG;
+    const int D = s->D;
+    if (n_out != (size_t)(1 + D + (size_t)D * D)) return KLHR_ERR_ARG;
+    HIPCHECK(s, hipSetDevice(s->cfg.device));
+    const int Dp = ((D + 1 + 15) / 16) * 16;
+    const long long nrows = (long long)n_iters * s->C;
+    double *d_G = nullptr;
+    HIPCHECK(s, hipMalloc((void **)&d_G, (size_t)Dp * Dp * 8));
+    int rc = 0;
+    {
+        hipError_t e = hipMemsetAsync(d_G, 0, (size_t)Dp * Dp * 8, s->stream);
+        if (e != hipSuccess) { s->err = hipGetErrorString(e); rc = KLHR_ERR_HIP; }
+    }
+    if (!rc) {
+        const int tiles = Dp / 16;
+        long long slabs = (nrows + 8191) / 8192;
+        if (slabs > 4096) slabs = 4096;
+        long long rps = (nrows + slabs - 1) / slabs;
+        rps = (rps + 3) / 4 * 4;
+        slabs = (nrows + rps - 1) / rps;
+        const double *X = s->d_draws + (size_t)first_iter * s->C * D;
+        hipLaunchKernelGGL(klhr_gram_mfma_kernel, dim3(tiles * tiles, (unsigned)slabs), dim3(64), 0, s->stream, X, nrows, D, Dp, rps, d_G);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { s->err = hipGetErrorString(e); rc = KLHR_ERR_HIP; }
+    }
+    std::vector<double> G((size_t)Dp * Dp);
+    if (!rc) rc = d2h(s, G.data(), d_G, G.size() * 8);
+    (void)hipFree(d_G);
+    if (rc) return rc;
+    auto g = [&](int i, int j) { return i <= j ? G[(size_t)i * Dp + j] : G[(size_t)j * Dp + i]; };   // upper-triangle tiles
+    out[0] = g(D, D);
+    for (int i = 0; i < D; i++) out[1 + i] = g(i, D);
+    for (int i = 0; i < D; i++)
+        for (int j = 0; j < D; j++) out[1 + D + (size_t)i * D + j] = 0.5 * (g(i, j) + g(j, i));
+    return KLHR_OK;
+}
+
+extern "C" int klhr_pool_apply_full(klhr_sampler *s, const double *mean, const double *cov_diag, const double *eigvecs, const double *eigvals) {
+    if (!s || !mean || !cov_diag || !eigvecs || !eigvals) return KLHR_ERR_ARG;
+    HIPCHECK(s, hipSetDevice(s->cfg.device));
+    const size_t D = s->D, nc = s->ncol;
+    double *d_m = nullptr;
+    const size_t tot = 2 * D + D * nc + nc;
+    HIPCHECK(s, hipMalloc((void **)&d_m, tot * 8));
+    int rc = h2d(s, d_m, mean, D * 8);
+    if (!rc) rc = h2d(s, d_m + D, cov_diag, D * 8);
+    if (!rc) rc = h2d(s, d_m + 2 * D, eigvecs, D * nc * 8);
+    if (!rc) rc = h2d(s, d_m + 2 * D + D * nc, eigvals, nc * 8);
+    if (!rc) {
+        const int bs = 64;
+        hipLaunchKernelGGL(klhr_pool_apply_full_kernel, dim3((s->C + bs - 1) / bs), dim3(bs), 0, s->stream, d_m, d_m + D, d_m + 2 * D,
+                           d_m + 2 * D + D * nc, s->kp.mean, s->kp.cov, s->kp.eigvecs, s->kp.eigvals, s->kp.rank, s->C, s->D, s->ncol);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { s->err = hipGetErrorString(e); rc = KLHR_ERR_HIP; }
+    }
+    if (!rc) rc = klhr_sync(s);
+    (void)hipFree(d_m);
+    return rc;
+}

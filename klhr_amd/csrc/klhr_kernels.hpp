@@ -725,6 +725,61 @@ __global__ void klhr_pool_kernel(const double *om_m, const double *om_v, const l
     if (threadIdx.x == 0) { out[1 + i] = red[0][0]; out[1 + D + i] = red[1][0]; if (i == 0) out[0] = red[2][0]; }
 }
 
+// Pooled FULL covariance (extension): Gram matrix of the recorded draws X [(n_iters*C) x D] on the matrix
+// cores.  G = Xa^T Xa with Xa = [X | 1] (the appended ones column yields the column sums and the row count for free).
+// One wavefront per (16x16 output tile, slab of rows); K = rows, 4 per v_mfma_f64_16x16x4_f64:
+//   A operand: lane l supplies Xa[r0 + l/16][ti*16 + l%16]   (A is 16(M) x 4(K): M index = l%16, K index = l/16)
+//   B operand: lane l supplies Xa[r0 + l/16][tj*16 + l%16]   (B is 4(K) x 16(N): N index = l%16, K index = l/16)
+//   D result : lane l holds D[4*r + l/16][l%16], r = 0..3   (verified against numpy in tests/test_gpu_api.py)
+// Slab partials are combined with fp64 atomic adds (order-dependent in the last bits: statistics, not parity data).
+typedef double klhr_d4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(64) void klhr_gram_mfma_kernel(const double *X, long long nrows, int D, int Dp, long long rows_per_slab,
+                                                            double *G /* Dp x Dp, zero-initialised */) {
+    const int lane = threadIdx.x & 63;
+    const int tiles = Dp / 16;
+    const int ti = blockIdx.x / tiles, tj = blockIdx.x % tiles;
+    if (tj < ti) return;                                    // symmetric: upper triangle of tiles only
+    const long long r_begin = (long long)blockIdx.y * rows_per_slab;
+    long long r_end = r_begin + rows_per_slab;
+    if (r_end > nrows) r_end = nrows;
+    const int ca = ti * 16 + (lane & 15), cb = tj * 16 + (lane & 15), kk = lane >> 4;
+    klhr_d4 acc = {0.0, 0.0, 0.0, 0.0};
+    for (long long r0 = r_begin; r0 < r_end; r0 += 4) {
+        const long long r = r0 + kk;
+        double a = 0.0, b = 0.0;
+        if (r < r_end) {
+            const double *row = X + r * (long long)D;
+            a = ca < D ? row[ca] : (ca == D ? 1.0 : 0.0);
+            b = cb < D ? row[cb] : (cb == D ? 1.0 : 0.0);
+        }
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    const int j = tj * 16 + (lane & 15);
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+        const int i = ti * 16 + 4 * rr + (lane >> 4);
+        atomicAdd(&G[(long long)i * Dp + j], acc[rr]);
+    }
+}
+
+__global__ void klhr_pool_apply_full_kernel(const double *mean_in, const double *cov_in, const double *evec_in, const double *eval_in,
+                                            double *mean, double *cov, double *eigvecs, double *eigvals, int *rank, int C, int D,
+                                            int ncol) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    for (int i = 0; i < D; i++) {
+        mean[c * (long long)D + i] = mean_in[i];
+        cov[c * (long long)D + i] = cov_in[i];
+        for (int j = 0; j < ncol; j++) eigvecs[(c * (long long)D + i) * ncol + j] = evec_in[i * ncol + j];
+    }
+    for (int j = 0; j < ncol; j++) eigvals[c * (long long)ncol + j] = eval_in[j];
+    for (int i = 0; i < D; i++) {
+        int r = 0;
+        for (int j = 0; j < D; j++) r += (cov_in[j] > cov_in[i] || (cov_in[j] == cov_in[i] && j < i)) ? 1 : 0;
+        rank[c * (long long)D + i] = r;
+    }
+}
+
 __global__ void klhr_pool_apply_kernel(const double *mean_in, const double *cov_in, double *mean, double *cov, int *rank, int C, int D) {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;

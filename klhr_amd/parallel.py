@@ -52,10 +52,37 @@ def pooled_moments(stats):
     return mean, np.maximum(var, 0.0)
 
 
+def pooled_full(stats, D, ncol):
+    """[n, sum x (D), sum x x^T (D*D)] -> pooled mean, covariance diagonal, top-`ncol` unit eigenvectors (D, ncol) and
+    eigenvalues (ncol, descending) of the pooled covariance.  Eigenvector signs are fixed (largest component positive)
+    so that every rank derives bit-identical values from the all-reduced statistics."""
+    stats = np.asarray(stats, dtype=np.float64)
+    n = stats[0]
+    mean = stats[1:1 + D] / n
+    S = stats[1 + D:].reshape(D, D) / n - np.outer(mean, mean)
+    S = 0.5 * (S + S.T) * n / max(n - 1.0, 1.0)
+    w, V = np.linalg.eigh(S)
+    order = np.argsort(-w)[:ncol]
+    vals = np.maximum(w[order], 0.0)
+    vecs = V[:, order]
+    sgn = np.sign(vecs[np.argmax(np.abs(vecs), axis=0), np.arange(vecs.shape[1])])
+    sgn[sgn == 0] = 1.0
+    vecs = vecs * sgn
+    if vecs.shape[1] < ncol:                      # D < ncol: pad
+        vecs = np.concatenate([vecs, np.zeros((D, ncol - vecs.shape[1]))], axis=1)
+        vals = np.concatenate([vals, np.ones(ncol - vals.size)])
+    return mean, np.maximum(np.diag(S), 0.0), np.ascontiguousarray(vecs), vals
+
+
 class ShardedKLHRSINH:
     """All chains of a multi-GPU job behind one object; every rank constructs it with the same arguments."""
 
+    SEGMENT = 50        # pooled="full": draws of at most this many iterations are kept on the device at a time
+
     def __init__(self, bsmodel, chains_total, seed=0, pooled=False, dist=None, **kw):
+        """pooled: False (parity mode, no collective) | True / "diag" (pool mean + per-coordinate variance) |
+        "full" (pool the full covariance: fp64 MFMA Gram of the window's draws per GPU, one all-reduce of
+        1 + D + D^2 doubles per window closure, eigen-decomposition on every rank)."""
         from .klhr_sinh import KLHRSINH
         self.rank, self.world, self.local_rank = dist_env()
         self.dist = dist
@@ -66,6 +93,8 @@ class ShardedKLHRSINH:
                               device=self.local_rank, overrelaxed=False, **kw)
         self._closures = list(self.local._windowedadaptation._closures)
         self._done = 0
+        self._full = pooled == "full"
+        self._gram = None
 
     def advance(self, n, record=False):
         """n iterations on this rank's shard.  Pooled mode stops in front of each window closure, all-reduces the
@@ -73,11 +102,17 @@ class ShardedKLHRSINH:
         s = self.local._sampler
         out = []
 
-        def run(k):
-            s.step(k, record_draws=record)
-            if record:
-                out.append(s.draws(0, k))
-            self._done += k
+        def run(k, accumulate=True):
+            while k > 0:
+                kk = min(k, self.SEGMENT) if self._full else k
+                s.step(kk, record_draws=record or self._full)
+                if record:
+                    out.append(s.draws(0, kk))
+                if self._full and accumulate:          # statistics of the open window (the closure draw is excluded)
+                    g = s.pool_gram(0, kk)
+                    self._gram = g if self._gram is None else self._gram + g
+                self._done += kk
+                k -= kk
 
         left = n
         while left > 0:
@@ -91,9 +126,19 @@ class ShardedKLHRSINH:
                 run(k)
                 left -= k
                 continue
-            tot = allreduce_sum(s.pool_stats(), self.dist, self.local_rank)
-            run(1)                                    # the closure iteration (klhr_sinh.py:268-280)
-            left -= 1
-            mean, var = pooled_moments(tot)
-            s.pool_apply(mean, var)
+            if self._full:
+                D = self.local.D
+                mine = self._gram if self._gram is not None else np.zeros(1 + D + D * D)
+                tot = allreduce_sum(mine, self.dist, self.local_rank)
+                run(1, accumulate=False)              # the closure iteration (klhr_sinh.py:268-280)
+                left -= 1
+                self._gram = None
+                if tot[0] > 2:
+                    s.pool_apply_full(*pooled_full(tot, D, s.ncol))
+            else:
+                tot = allreduce_sum(s.pool_stats(), self.dist, self.local_rank)
+                run(1)                                # the closure iteration
+                left -= 1
+                mean, var = pooled_moments(tot)
+                s.pool_apply(mean, var)
         return np.concatenate(out) if record else None

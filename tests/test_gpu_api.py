@@ -169,3 +169,43 @@ def test_pooled_adaptation_single_rank():
     sp.advance(51)
     m2 = sp.local._sampler.get("mean")
     assert not np.all(m2 == m2[0])
+
+
+def test_mfma_gram_kernel_vs_numpy():
+    """klhr_pool_gram: fp64 MFMA Gram product over recorded draws == numpy X^T X (plus column sums and the row count)."""
+    from klhr_amd import _lib
+    for D_alpha, C in ((9, 96), (99, 40)):
+        s = _lib.Sampler(_lib.MODEL_IDS["funnel"], np.array([float(D_alpha)]), C, warmup=100)
+        s.seed(np.arange(C, dtype=np.uint64) + 5)
+        n = 7
+        s.step(n, record_draws=True)
+        X = s.draws(0, n).reshape(-1, s.D)
+        g = s.pool_gram(0, n)
+        D = s.D
+        assert g[0] == n * C
+        assert np.allclose(g[1:1 + D], X.sum(axis=0), rtol=1e-12, atol=1e-12)
+        G = g[1 + D:].reshape(D, D)
+        assert np.allclose(G, X.T @ X, rtol=1e-12, atol=1e-10)
+        g2 = s.pool_gram(2, 3)                       # a sub-range of the buffer
+        X2 = s.draws(2, 3).reshape(-1, D)
+        assert np.allclose(g2[1 + D:].reshape(D, D), X2.T @ X2, rtol=1e-12, atol=1e-10) and g2[0] == 3 * C
+
+
+def test_pooled_full_covariance_single_rank():
+    from klhr_amd.parallel import ShardedKLHRSINH, pooled_full
+    sh = ShardedKLHRSINH(funnel_model(), 256, seed=9, pooled="full", warmup=100)
+    dr = sh.advance(49, record=True)
+    s = sh.local._sampler
+    X = dr.reshape(-1, 10)
+    assert np.allclose(sh._gram[1 + 10:].reshape(10, 10), X.T @ X, rtol=1e-11, atol=1e-9)
+    sh.advance(2)                      # crosses the closure at draw 50 -> pooled mean / cov / eigvecs on every chain
+    mean, cov, evec, evals = s.get("mean"), s.get("cov"), s.get("eigvecs"), s.get("eigvals")
+    assert np.all(mean == mean[0]) and np.all(evec == evec[0]) and np.all(evals == evals[0])
+    S = np.cov(X.T)
+    w, V = np.linalg.eigh(S)
+    assert np.allclose(mean[0], X.mean(axis=0), rtol=1e-10)
+    assert np.allclose(cov[0], np.diag(S), rtol=1e-9)
+    assert np.allclose(evals[0], w[::-1][:2], rtol=1e-8)
+    assert abs(abs(evec[0][:, 0] @ V[:, -1]) - 1) < 1e-8
+    sh.advance(60)                     # keeps sampling through the second closure with pooled directions
+    assert np.isfinite(s.get("theta")).all()

@@ -26,11 +26,15 @@ mine = X[lo:hi]
 stats = np.concatenate([[mine.shape[0] * mine.shape[1]], mine.sum(axis=(0, 1)), (mine ** 2).sum(axis=(0, 1))])
 tot = P.allreduce_sum(stats, dist)
 mean, var = P.pooled_moments(tot)
+flat = mine.reshape(-1, D)
+gram = np.concatenate([[flat.shape[0]], flat.sum(axis=0), (flat.T @ flat).reshape(-1)])
+fm, fdiag, fvec, fval = P.pooled_full(P.allreduce_sum(gram, dist), D, 2)
 t = P.allreduce_sum(np.array([float(rank + 1)]), dist)
 dist.barrier()
 with open(os.path.join(os.environ["KLHR_OUT"], f"result_{rank}.json"), "w") as f:
     json.dump({"rank": rank, "lo": lo, "hi": hi, "seeds": [int(s) for s in seeds], "mean": mean.tolist(),
-               "var": var.tolist(), "sum": float(t[0])}, f)
+               "var": var.tolist(), "sum": float(t[0]), "fm": fm.tolist(), "fdiag": fdiag.tolist(), "fvec": fvec.tolist(),
+               "fval": fval.tolist()}, f)
 dist.destroy_process_group()
 '''
 
@@ -53,6 +57,12 @@ def test_two_rank_gloo_sharding_and_pooling(tmp_path):
         assert np.allclose(r["mean"], flat.mean(axis=0), rtol=1e-12)
         assert np.allclose(r["var"], flat.var(axis=0, ddof=1), rtol=1e-10)
         assert r["sum"] == 3.0
+        S = np.cov(flat.T)
+        w, V = np.linalg.eigh(S)
+        assert np.allclose(r["fm"], flat.mean(axis=0), rtol=1e-12) and np.allclose(r["fdiag"], np.diag(S), rtol=1e-10)
+        assert np.allclose(r["fval"], w[::-1][:2], rtol=1e-9)
+        assert abs(abs(np.array(r["fvec"])[:, 0] @ V[:, -1]) - 1) < 1e-9
+    assert res[0]["fvec"] == res[1]["fvec"]          # every rank derives bit-identical pooled directions
 
 
 def test_shard_ranges_cover_everything():
