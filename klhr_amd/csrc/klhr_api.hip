@@ -280,29 +280,34 @@ extern "C" int klhr_sync(klhr_sampler *s) {
 }
 
 // ---- launches ------------------------------------------------------------------------------------
-static int launch_iter(klhr_sampler *s, const KParams &kp_in) {
-    KParams kp = kp_in;
-    if (s->use_lane) {
-        kp.S = s->S_lane;
+template <bool OVERRELAX>
+static void launch_iter_t(klhr_sampler *s, const KParams &kp, bool lane) {
+    if (lane) {
         const dim3 grid((kp.C + 63) / 64), block(64);
         const size_t lds = (size_t)64 * kp.S * sizeof(double);
         switch (s->cfg.model_id) {
-        case KLHR_MODEL_FUNNEL: hipLaunchKernelGGL(klhr_lane_kernel<MODEL_FUNNEL>, grid, block, lds, s->stream, kp); break;
-        case KLHR_MODEL_ILL_NORMAL: hipLaunchKernelGGL(klhr_lane_kernel<MODEL_ILL_NORMAL>, grid, block, lds, s->stream, kp); break;
-        case KLHR_MODEL_GLMM_POISSON: hipLaunchKernelGGL(klhr_lane_kernel<MODEL_GLMM_POISSON>, grid, block, lds, s->stream, kp); break;
-        default: hipLaunchKernelGGL(klhr_lane_kernel<MODEL_NORMAL>, grid, block, lds, s->stream, kp); break;
+        case KLHR_MODEL_FUNNEL: hipLaunchKernelGGL((klhr_lane_kernel<MODEL_FUNNEL, OVERRELAX>), grid, block, lds, s->stream, kp); break;
+        case KLHR_MODEL_ILL_NORMAL: hipLaunchKernelGGL((klhr_lane_kernel<MODEL_ILL_NORMAL, OVERRELAX>), grid, block, lds, s->stream, kp); break;
+        case KLHR_MODEL_GLMM_POISSON: hipLaunchKernelGGL((klhr_lane_kernel<MODEL_GLMM_POISSON, OVERRELAX>), grid, block, lds, s->stream, kp); break;
+        default: hipLaunchKernelGGL((klhr_lane_kernel<MODEL_NORMAL, OVERRELAX>), grid, block, lds, s->stream, kp); break;
         }
     } else {
-        kp.S = s->S;
         const dim3 grid((kp.C + 7) / 8), block(64);
         const size_t lds = (size_t)8 * kp.S * sizeof(double);
         switch (s->cfg.model_id) {
-        case KLHR_MODEL_FUNNEL: hipLaunchKernelGGL(klhr_iter_kernel<MODEL_FUNNEL>, grid, block, lds, s->stream, kp); break;
-        case KLHR_MODEL_ILL_NORMAL: hipLaunchKernelGGL(klhr_iter_kernel<MODEL_ILL_NORMAL>, grid, block, lds, s->stream, kp); break;
-        case KLHR_MODEL_GLMM_POISSON: hipLaunchKernelGGL(klhr_iter_kernel<MODEL_GLMM_POISSON>, grid, block, lds, s->stream, kp); break;
-        default: hipLaunchKernelGGL(klhr_iter_kernel<MODEL_NORMAL>, grid, block, lds, s->stream, kp); break;
+        case KLHR_MODEL_FUNNEL: hipLaunchKernelGGL((klhr_iter_kernel<MODEL_FUNNEL, OVERRELAX>), grid, block, lds, s->stream, kp); break;
+        case KLHR_MODEL_ILL_NORMAL: hipLaunchKernelGGL((klhr_iter_kernel<MODEL_ILL_NORMAL, OVERRELAX>), grid, block, lds, s->stream, kp); break;
+        case KLHR_MODEL_GLMM_POISSON: hipLaunchKernelGGL((klhr_iter_kernel<MODEL_GLMM_POISSON, OVERRELAX>), grid, block, lds, s->stream, kp); break;
+        default: hipLaunchKernelGGL((klhr_iter_kernel<MODEL_NORMAL, OVERRELAX>), grid, block, lds, s->stream, kp); break;
         }
     }
+}
+
+static int launch_iter(klhr_sampler *s, const KParams &kp_in) {
+    KParams kp = kp_in;
+    kp.S = s->use_lane ? s->S_lane : s->S;
+    if (s->cfg.overrelaxed) launch_iter_t<true>(s, kp, s->use_lane);
+    else launch_iter_t<false>(s, kp, s->use_lane);
     HIPCHECK(s, hipGetLastError());
     return 0;
 }

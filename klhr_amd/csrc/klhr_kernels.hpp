@@ -352,7 +352,7 @@ __device__ inline void close_window(const KParams &p, long long c, long long omN
 #pragma clang fp contract(fast)
 
 // ------------------------------------------------------------------------------------------------
-template <int MODEL>
+template <int MODEL, bool OVERRELAX>
 #ifdef KLHR_OCTET_LB2
 __global__ __launch_bounds__(64, 2) void klhr_iter_kernel(const KParams p)
 #else
@@ -487,8 +487,9 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
         // =============================================================== MH step (klhr_sinh.py:242-260)
         if (p.phases & PH_MH) {
             draw += 1;
-            const double zp = (p.flags & FLAG_OVERRELAXED) ? overrelaxed_zp(rng, eta, p.K, p.tol, p.scale_clip)
-                                                           : sa_T(rng_std_normal(rng), eta, p.tol, p.scale_clip);
+            double zp;
+            if constexpr (OVERRELAX) zp = overrelaxed_zp(rng, eta, p.K, p.tol, p.scale_clip);
+            else zp = sa_T(rng_std_normal(rng), eta, p.tol, p.scale_clip);
             double logp, gdot;
             const double t = (l8 == 0) ? zp : 0.0;
             model_eval<MODEL>(p.md, [&](int i, double &xi, double &ri) { double2 v = TR[i]; ri = v.y; xi = fma(t, v.y, v.x); },

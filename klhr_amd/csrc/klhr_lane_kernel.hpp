@@ -203,7 +203,9 @@ __device__ __forceinline__ void lane_eval_line(const KParams &p, const double2 *
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int MODEL>
+// OVERRELAX is a compile-time switch: the over-relaxed proposal's code (binomial/beta loops, Phi, Phi^-1) would otherwise
+// sit in the register allocation of every launch (measured: +1.5 KB scratch per lane, -8 % throughput).
+template <int MODEL, bool OVERRELAX>
 __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x & 63;
@@ -337,8 +339,9 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
         // =============================================================== MH step
         if ((p.phases & PH_MH) && active) {
             draw += 1;
-            const double zp = (p.flags & FLAG_OVERRELAXED) ? overrelaxed_zp(rng, eta, p.K, p.tol, p.scale_clip)
-                                                           : sa_T(rng_std_normal(rng), eta, p.tol, p.scale_clip);
+            double zp;
+            if constexpr (OVERRELAX) zp = overrelaxed_zp(rng, eta, p.K, p.tol, p.scale_clip);
+            else zp = sa_T(rng_std_normal(rng), eta, p.tol, p.scale_clip);
             double t2[2] = {zp, 0.0}, lp2[2], gd2[2];
             model_eval_nv<MODEL, 2>(p.md, TR, t2, INFINITY, lp2, gd2);
             double r = lp2[0];
