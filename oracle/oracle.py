@@ -61,6 +61,8 @@ def lib():
         L.klhr_oracle_primitives_inv.argtypes = [vp, C.c_double, dp, dp]
         L.klhr_oracle_get.argtypes = [vp, C.c_int, vp]
         L.klhr_oracle_set.argtypes = [vp, C.c_int, vp]
+        L.klhr_oracle_set_variant.argtypes = [vp, C.c_int]
+        L.klhr_oracle_get_K.argtypes = [vp]
         L.klhr_oracle_ndtr.argtypes = [C.c_double]
         L.klhr_oracle_ndtr.restype = C.c_double
         L.klhr_oracle_ndtri.argtypes = [C.c_double]
@@ -113,7 +115,7 @@ class Chain:
 
     def __init__(self, stem, data, seed=None, N=8, K=10, J=2, l=4, initscale=0.1, warmup=1000, windowsize=50,
                  windowscale=2, tol=1e-10, grad_clip=1e15, scale_clip=300, scale_dir_cov=False, overrelaxed=False,
-                 eigen_method_one=False, max_init_tries=100, theta_given=False):
+                 eigen_method_one=False, max_init_tries=100, theta_given=False, variant="sinh"):
         L = lib()
         self._L = L
         self._data = np.ascontiguousarray(model_data(stem, data), dtype=np.float64)
@@ -127,6 +129,9 @@ class Chain:
         if not self._h:
             raise ValueError("oracle: bad configuration")
         self.D = L.klhr_oracle_dim(self._h)
+        self.variant = variant
+        if variant == "gauss":
+            L.klhr_oracle_set_variant(self._h, 1)
         self.init_tries = None
         if seed is not None:
             self.init_tries = L.klhr_oracle_seed(self._h, int(seed), None)
@@ -238,6 +243,15 @@ class Chain:
         out = np.zeros((n, self.D))
         self._L.klhr_oracle_mh_draw(self._h, float(stepsize), n, _dp(out))
         return out
+
+
+def KLHRChain(stem, data, seed=None, **kw):
+    """A chain of the Gaussian-proposal sampler with klhr.py's constructor defaults (klhr.py:16-34)."""
+    d = dict(tol=1e-12, scale_clip=600, overrelaxed=False, eigen_method_one=True, variant="gauss")
+    d.update(kw)
+    D = {"funnel": lambda: data["D"] + 1, "glmm-poisson": lambda: data["n"] + 5}.get(stem, lambda: data["D"])()
+    d["J"] = min(d.get("J", 2), D - 1)          # klhr.py:39
+    return Chain(stem, data, seed=seed, **d)
 
 
 def draw_batch(chains, niters):

@@ -33,6 +33,7 @@ sys.path.insert(0, REF)
 sys.path.insert(0, ROOT)
 
 import klhr_sinh as ref_klhr_sinh          # noqa: E402  (reference)
+import klhr as ref_klhr                    # noqa: E402  (reference, Gaussian-proposal sibling)
 import mh as ref_mh                        # noqa: E402
 import onlinemoments as ref_om             # noqa: E402
 import onlinepca as ref_pca                # noqa: E402
@@ -361,6 +362,112 @@ def trace_chain(name, seed, M, warmup, **flags):
     return out
 
 
+def trace_chain_klhr(name, seed, M, warmup, **flags):
+    """The same per-iteration trace for the reference's Gaussian-proposal sampler KLHR (klhr.py:197-223)."""
+    model = make_model(name)
+    algo = ref_klhr.KLHR(model, seed=seed, warmup=warmup, **flags)
+    D = algo.D
+    keys = ["state_before", "theta_before", "rho", "x0", "mode", "hinv1", "nfev1", "nit1", "status1", "init", "eta", "nfev2",
+            "nit2", "status2", "fun2", "state_mh", "zp", "r", "logu", "accept", "theta_after", "accprob", "grad_evals",
+            "state_after", "K"]
+    rec = {k: [] for k in keys}
+    snaps = {}
+    theta0 = algo.theta.copy()
+    results = []
+    real_minimize = ref_klhr.minimize
+
+    def rec_minimize(fun, x0, *a, **k):
+        x0c = np.array(x0, dtype=np.float64).reshape(-1).copy()
+        o = real_minimize(fun, x0, *a, **k)
+        results.append((o, x0c))
+        return o
+
+    ref_klhr.minimize = rec_minimize
+    try:
+        for m in range(1, M + 1):
+            rec["state_before"].append(st4(algo.rng))
+            th0 = algo.theta.copy()
+            rec["theta_before"].append(th0)
+            algo._draw += 1
+            rho = algo._random_direction()
+            results.clear()
+            eta = algo.fit(rho)
+            (o1, x01), (o2, x02) = results
+            rec["x0"].append(float(x01[0])); rec["init"].append(x02)
+            rec["rho"].append(rho.copy()); rec["mode"].append(float(o1.x[0])); rec["hinv1"].append(float(o1.hess_inv[0, 0]))
+            rec["nfev1"].append(o1.nfev); rec["nit1"].append(o1.nit); rec["status1"].append(o1.status)
+            rec["eta"].append(eta.copy()); rec["nfev2"].append(o2.nfev); rec["nit2"].append(o2.nit)
+            rec["status2"].append(o2.status); rec["fun2"].append(float(o2.fun))
+            rec["state_mh"].append(st4(algo.rng))
+            rc = clone_rng(algo.rng)
+            mm, ss = algo._unpack(eta)
+            with np.errstate(all="ignore"):
+                zp = rc.normal(loc=mm, scale=ss, size=1)
+                thetap = zp * rho + th0
+                r = model.log_density(thetap)
+                r -= model.log_density(th0)
+                r += algo._logq(0, eta)
+                r -= algo._logq(zp, eta)
+                logu = np.log(rc.uniform())
+                theta = algo._metropolis_step(eta, rho)
+            rec["zp"].append(float(zp[0])); rec["r"].append(float(np.asarray(r).reshape(-1)[0])); rec["logu"].append(float(logu))
+            rec["accept"].append(bool(logu < np.minimum(0, r)))
+            assert np.array_equal(st4(rc), st4(algo.rng))
+            if algo._windowedadaptation.window_closed(algo._draw):          # klhr.py:203-214
+                algo._mean = algo._onlinemoments.mean()
+                algo._cov = algo._onlinemoments.var()
+                if algo._scale_dir_cov:
+                    algo._cov /= (algo._tol + algo._onlinemoments_density.var())
+                algo._onlinemoments_density.reset()
+                algo._onlinemoments.reset()
+                algo._eigvecs[:, :algo.J] = algo._onlinepca.vectors()
+                algo._eigvals[:algo.J] = algo._onlinepca.values()
+                algo._onlinepca.reset()
+                K = algo._smoothK.optimum()
+                algo.K = int(np.clip(K, 1, 50))
+                algo._smoothK.reset()
+            else:                                                              # klhr.py:215-221
+                _, g = model.log_density_gradient(theta)
+                algo._onlinemoments_density.update(g)
+                algo._onlinemoments.update(theta)
+                algo._onlinepca.update(theta - algo._mean)
+                msjd = np.linalg.norm(theta - algo._prev_theta)
+                algo._smoothK.update(2 * (msjd > algo._msjd) - 1)
+            rec["theta_after"].append(np.array(theta, dtype=np.float64).copy())
+            rec["accprob"].append(float(np.asarray(algo.acceptance_probability).reshape(-1)[0]))
+            rec["grad_evals"].append(int(algo.grad_evals)); rec["state_after"].append(st4(algo.rng)); rec["K"].append(int(algo.K))
+            if m in SNAP_DRAWS:
+                snaps[m] = dict(mean=np.array(algo._mean, dtype=np.float64).copy(), cov=np.array(algo._cov, dtype=np.float64).copy(),
+                                eigvecs=algo._eigvecs.copy(), eigvals=algo._eigvals.copy(), om_N=algo._onlinemoments.N,
+                                om_m=algo._onlinemoments.m.copy(), om_v=algo._onlinemoments.v.copy(),
+                                pca_n=algo._onlinepca.n, pca_v=algo._onlinepca.v.copy(), smooth_x=float(algo._smoothK._x))
+    finally:
+        ref_klhr.minimize = real_minimize
+    out = {"theta0": theta0, "seed": np.array([seed]), "M": np.array([M]), "warmup": np.array([warmup]), "D": np.array([D]),
+           "J": np.array([algo.J])}
+    for k, v in rec.items():
+        out[k] = np.array(v)
+    out["snap_draws"] = np.array(sorted(snaps), dtype=np.int64)
+    for m, sdict in snaps.items():
+        for k, v in sdict.items():
+            out[f"snap{m}_{k}"] = np.asarray(v)
+    return out
+
+
+def g11_klhr():
+    for name, seed, M, warmup, flags in [("funnel10", 0, 400, 100, {}), ("funnel10", 1, 400, 100, {"eigen_method_one": False}),
+                                         ("normal2", 0, 300, 100, {}), ("illnormal100", 0, 130, 100, {})]:
+        tag = "" if flags.get("eigen_method_one", True) else "_m2"
+        fn = os.path.join(HERE, f"g11_klhr_{name}_s{seed}_w{warmup}{tag}.npz")
+        print("tracing", fn, flush=True)
+        np.savez(fn, **trace_chain_klhr(name, seed, M, warmup, **flags))
+    # public API: untouched draw() loop guards the step-by-step replication above
+    algo = ref_klhr.KLHR(make_model("funnel10"), seed=0, warmup=100)
+    th = np.array([algo.draw() for _ in range(120)])
+    np.savez(os.path.join(HERE, "g11_klhr_public_api.npz"), s0_thetas=th, s0_K=np.array([algo.K]),
+             s0_grad_evals=np.array([algo.grad_evals]))
+
+
 def g8_chains():
     jobs = []
     for seed in range(4):
@@ -428,9 +535,9 @@ def g10_overrelaxed():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g7", "g8", "g8p", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g7", "g8", "g8p", "g9", "g10", "g11"]
     fns = {"g1": g1_quadrature, "g2": g2_rng, "g3": g3_primitives, "g4": g4_kl, "g7": g7_online,
-           "g8": g8_chains, "g8p": g8_untouched, "g9": g9_mh, "g10": g10_overrelaxed}
+           "g8": g8_chains, "g8p": g8_untouched, "g9": g9_mh, "g10": g10_overrelaxed, "g11": g11_klhr}
     for w in which:
         print("==", w, flush=True)
         fns[w]()
