@@ -64,7 +64,8 @@ typedef struct klhr_config {
     int32_t scale_dir_cov, overrelaxed, eigen_method_one;   /* overrelaxed: binomial/beta variates come from the
                                                               * chain's own PCG64 stream (the reference uses SciPy's unseeded
                                                               * global RNG there: distribution-exact, not stream-exact) */
-    int32_t reserved;
+    int32_t variant;           /* 0: KLHRSINH, 4-parameter sinh-arcsinh proposal (klhr_sinh.py)
+                                * 1: KLHR, 2-parameter Gaussian proposal (klhr.py:15-223); eta is then (m, log s, 0, 0) */
     const double *quad_x;      /* N probabilists' Gauss-Hermite nodes   (klhr_sinh.py:44-47) */
     const double *quad_w;      /* N weights                                                  */
     const double *quad_asinh_x;/* N values asinh(x_n) (host-computed, np.arcsinh)            */
@@ -142,7 +143,8 @@ enum klhr_field {
     KLHR_F_RHO = 14,       /* double  C×D  last direction (record_diag) */
     KLHR_F_ETA = 15,       /* double  C×4  last fitted eta (record_diag) */
     KLHR_F_DIAG = 16,      /* double  C×KLHR_NDIAG (record_diag), layout below */
-    KLHR_F_STATUS = 17     /* int32   C    bit0 init failed, bit1 theta non-finite */
+    KLHR_F_STATUS = 17,    /* int32   C    bit0 init failed, bit1 theta non-finite */
+    KLHR_F_KSTATE = 18     /* double  C×4  KLHR variant: [Smoother x, Smoother count, current K, moved flag] (klhr.py:212-221) */
 };
 /* KLHR_F_DIAG columns */
 enum { KLHR_D_X0 = 0, KLHR_D_MODE, KLHR_D_HINV1, KLHR_D_NFEV1, KLHR_D_NIT1, KLHR_D_STATUS1, KLHR_D_INIT0, KLHR_D_INIT1,

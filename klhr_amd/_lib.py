@@ -12,7 +12,7 @@ NDIAG = 20
 DIAG_COLS = ["x0", "mode", "hinv1", "nfev1", "nit1", "status1", "init0", "init1", "init2", "init3", "nfev2", "nit2",
              "status2", "fun2", "zp", "r", "logu", "accept", "fallbacks", "passes"]
 FIELDS = dict(theta=0, rng=1, mean=2, cov=3, eigvecs=4, eigvals=5, om_m=6, om_v=7, omd_m=8, omd_v=9, pca_v=10, counters=11,
-              acc=12, grad_evals=13, rho=14, eta=15, diag=16, status=17)
+              acc=12, grad_evals=13, rho=14, eta=15, diag=16, status=17, kstate=18)
 MODEL_IDS = {"funnel": 0, "ill-normal": 1, "glmm-poisson": 2, "normal": 3}
 
 
@@ -27,7 +27,7 @@ class Config(C.Structure):
                 ("scale_clip", C.c_double),
                 ("warmup", C.c_int64), ("windowsize", C.c_int64), ("windowscale", C.c_int64),
                 ("scale_dir_cov", C.c_int32), ("overrelaxed", C.c_int32), ("eigen_method_one", C.c_int32),
-                ("reserved", C.c_int32),
+                ("variant", C.c_int32),
                 ("quad_x", C.POINTER(C.c_double)), ("quad_w", C.POINTER(C.c_double)),
                 ("quad_asinh_x", C.POINTER(C.c_double))]
 
@@ -119,7 +119,7 @@ class Sampler:
 
     def __init__(self, model_id, model_data, chains, device=0, N=8, K=10, J=2, l=4, initscale=0.1, warmup=1000,
                  windowsize=50, windowscale=2, tol=1e-10, grad_clip=1e15, scale_clip=300, scale_dir_cov=False,
-                 overrelaxed=False, eigen_method_one=False, max_init_tries=100, quad=None):
+                 overrelaxed=False, eigen_method_one=False, max_init_tries=100, quad=None, variant=0):
         L = lib()
         self._L = L
         self._h = C.c_void_p()
@@ -143,6 +143,7 @@ class Sampler:
         cfg.warmup, cfg.windowsize, cfg.windowscale = int(warmup), int(windowsize), int(windowscale)
         cfg.scale_dir_cov, cfg.overrelaxed, cfg.eigen_method_one = int(bool(scale_dir_cov)), int(bool(overrelaxed)), \
             int(bool(eigen_method_one))
+        cfg.variant = int(variant)
         cfg.quad_x, cfg.quad_w, cfg.quad_asinh_x = dptr(self.x), dptr(self.w), dptr(self._asx)
         rc = L.klhr_create(C.byref(cfg), dptr(self._data), self._data.size, C.byref(self._h))
         if rc != 0:
@@ -256,7 +257,7 @@ class Sampler:
                 "omd_m": ((C_, D), np.float64), "omd_v": ((C_, D), np.float64), "pca_v": ((C_, D, self.J), np.float64),
                 "counters": ((C_, 4), np.int64), "acc": ((C_,), np.float64), "grad_evals": ((C_,), np.int64),
                 "rho": ((C_, D), np.float64), "eta": ((C_, 4), np.float64), "diag": ((C_, NDIAG), np.float64),
-                "status": ((C_,), np.int32)}[name]
+                "status": ((C_,), np.int32), "kstate": ((C_, 4), np.float64)}[name]
 
     def get(self, name):
         shape, dt = self._shape(name)

@@ -1,4 +1,7 @@
-"""Build libklhr_hip.so for gfx950 in-tree (klhr_amd/lib/).  `python -m klhr_amd.build [--force]`"""
+"""Build libklhr_hip.so for gfx950 in-tree (klhr_amd/lib/).  `python -m klhr_amd.build [--force] [-v]`
+
+Five translation units are compiled in parallel and linked: klhr_api.hip (C ABI + small kernels) and klhr_hot.hip four
+times, once per (sampler variant, over-relaxation) pair — see the comment at the top of klhr_hot.hip."""
 import os
 import subprocess
 import sys
@@ -6,9 +9,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libklhr_hip.so")
-SOURCES = ["klhr_api.hip"]
-DEPS = ["klhr_api.hip", "klhr_kernels.hpp", "klhr_lane_kernel.hpp", "device_opt.hpp", "device_models.hpp", "device_rng.hpp", "zig_tables.h",
-        os.path.join("..", "..", "include", "klhr.h")]
+OBJ = os.path.join(HERE, "lib", "obj")
+DEPS = ["klhr_api.hip", "klhr_hot.hip", "klhr_kernels.hpp", "klhr_lane_kernel.hpp", "device_opt.hpp", "device_models.hpp",
+        "device_rng.hpp", "zig_tables.h", os.path.join("..", "..", "include", "klhr.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"]
 
 
 def needs_build():
@@ -18,16 +22,29 @@ def needs_build():
     return any(os.path.getmtime(os.path.join(SRC, d)) > t for d in DEPS)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, extra=()):
     if not force and not needs_build():
         return OUT
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    os.makedirs(OBJ, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
-           "-o", OUT] + [os.path.join(SRC, s) for s in SOURCES]
-    if verbose:
-        cmd.append("-Rpass-analysis=kernel-resource-usage")
-    subprocess.check_call(cmd)
+    flags = FLAGS + list(extra) + (["-Rpass-analysis=kernel-resource-usage"] if verbose else [])
+    jobs = [("api.o", ["-c", os.path.join(SRC, "klhr_api.hip")])]
+    for v in (0, 1):
+        for o in (0, 1):
+            jobs.append((f"hot_v{v}_o{o}.o", ["-c", os.path.join(SRC, "klhr_hot.hip"), f"-DKLHR_VARIANT={v}", f"-DKLHR_OVERRELAX={o}"]))
+    procs = []
+    for name, args in jobs:
+        cmd = [hipcc] + flags + args + ["-o", os.path.join(OBJ, name)]
+        procs.append((name, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    failed = False
+    for name, pr in procs:
+        out, _ = pr.communicate()
+        if verbose or pr.returncode != 0:
+            sys.stderr.write(out)
+        failed |= pr.returncode != 0
+    if failed:
+        raise RuntimeError("hipcc failed")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + [os.path.join(OBJ, n) for n, _ in jobs])
     return OUT
 
 

@@ -13,7 +13,13 @@
 #include <vector>
 
 #include "klhr_kernels.hpp"
-#include "klhr_lane_kernel.hpp"
+
+namespace klhr {   // hot-path launchers, one per (variant, over-relaxation) translation unit (klhr_hot.hip)
+void launch_hot_v0_o0(const KParams &, int, bool, hipStream_t);
+void launch_hot_v0_o1(const KParams &, int, bool, hipStream_t);
+void launch_hot_v1_o0(const KParams &, int, bool, hipStream_t);
+void launch_hot_v1_o1(const KParams &, int, bool, hipStream_t);
+}  // namespace klhr
 
 using namespace klhr;
 
@@ -161,6 +167,11 @@ static int reset_state(klhr_sampler *s) {
     HIPCHECK(s, hipMemsetAsync(k.d_rho, 0, C * D * 8, s->stream));
     HIPCHECK(s, hipMemsetAsync(k.d_eta, 0, C * 4 * 8, s->stream));
     HIPCHECK(s, hipMemsetAsync(k.d_diag, 0, C * KLHR_NDIAG * 8, s->stream));
+    {   // KLHR variant: Smoother(K) state per chain = [x = K, count = 0, K, moved = 0]
+        std::vector<double> ks(C * 4, 0.0);
+        for (size_t c = 0; c < C; c++) { ks[c * 4 + 0] = (double)s->cfg.K; ks[c * 4 + 2] = (double)s->cfg.K; }
+        HIPCHECK(s, hipMemcpyAsync(k.kstate, ks.data(), C * 4 * 8, hipMemcpyHostToDevice, s->stream));
+    }
     HIPCHECK(s, hipStreamSynchronize(s->stream));
     return 0;
 }
@@ -173,6 +184,7 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
     if (cfg->J < 1 || cfg->J > 3) return fail("klhr_create: need 1 <= J <= 3");
     if (cfg->overrelaxed && (cfg->K < 1 || cfg->K > 64)) return fail("klhr_create: overrelaxed needs 1 <= K <= 64");
     if (cfg->chains < 1) return fail("klhr_create: chains < 1");
+    if (cfg->variant != 0 && cfg->variant != 1) return fail("klhr_create: variant must be 0 (KLHRSINH) or 1 (KLHR)");
     if (!model_data || n_model_data < 1 || !cfg->quad_x || !cfg->quad_w || !cfg->quad_asinh_x) return fail("klhr_create: null data");
     int D = 0, n = 0;
     std::vector<double> aux;
@@ -232,7 +244,8 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
               (cfg->overrelaxed ? FLAG_OVERRELAXED : 0);
     k.K = cfg->K;
     k.tol = cfg->tol; k.scale_clip = cfg->scale_clip; k.initscale = cfg->initscale; k.l = cfg->l;
-    for (int i = 0; i < 8; i++) { k.wq[i] = cfg->quad_w[i]; k.asx[i] = cfg->quad_asinh_x[i]; }
+    for (int i = 0; i < 8; i++) { k.xq[i] = cfg->quad_x[i]; k.wq[i] = cfg->quad_w[i]; k.asx[i] = cfg->quad_asinh_x[i]; }
+    k.variant = cfg->variant;
     TRY(dalloc(s, &s->d_aux, aux.size()));
     if (!aux.empty()) TRY(hip_try(hipMemcpy(s->d_aux, aux.data(), aux.size() * 8, hipMemcpyHostToDevice), "hipMemcpy aux"));
     k.md.aux = s->d_aux; k.md.D = D; k.md.n = n;
@@ -243,6 +256,7 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
     TRY(dalloc(s, &k.pca_v, C * D * J)); TRY(dalloc(s, &k.acc, C)); TRY(dalloc(s, &k.rank, C * D));
     TRY(dalloc(s, &k.counters, C * 4)); TRY(dalloc(s, &k.grad_evals, C)); TRY(dalloc(s, &k.status, C));
     TRY(dalloc(s, &k.d_rho, C * D)); TRY(dalloc(s, &k.d_eta, C * 4)); TRY(dalloc(s, &k.d_diag, C * KLHR_NDIAG));
+    TRY(dalloc(s, &k.kstate, C * 4));
     k.warmup = cfg->warmup; k.windowsize = cfg->windowsize;
     int64_t cl[40];
     int ncl = klhr_window_closures(cfg->warmup, cfg->windowsize, cfg->windowscale, cl, 40);
@@ -280,34 +294,12 @@ extern "C" int klhr_sync(klhr_sampler *s) {
 }
 
 // ---- launches ------------------------------------------------------------------------------------
-template <bool OVERRELAX>
-static void launch_iter_t(klhr_sampler *s, const KParams &kp, bool lane) {
-    if (lane) {
-        const dim3 grid((kp.C + 63) / 64), block(64);
-        const size_t lds = (size_t)64 * kp.S * sizeof(double);
-        switch (s->cfg.model_id) {
-        case KLHR_MODEL_FUNNEL: hipLaunchKernelGGL((klhr_lane_kernel<MODEL_FUNNEL, OVERRELAX>), grid, block, lds, s->stream, kp); break;
-        case KLHR_MODEL_ILL_NORMAL: hipLaunchKernelGGL((klhr_lane_kernel<MODEL_ILL_NORMAL, OVERRELAX>), grid, block, lds, s->stream, kp); break;
-        case KLHR_MODEL_GLMM_POISSON: hipLaunchKernelGGL((klhr_lane_kernel<MODEL_GLMM_POISSON, OVERRELAX>), grid, block, lds, s->stream, kp); break;
-        default: hipLaunchKernelGGL((klhr_lane_kernel<MODEL_NORMAL, OVERRELAX>), grid, block, lds, s->stream, kp); break;
-        }
-    } else {
-        const dim3 grid((kp.C + 7) / 8), block(64);
-        const size_t lds = (size_t)8 * kp.S * sizeof(double);
-        switch (s->cfg.model_id) {
-        case KLHR_MODEL_FUNNEL: hipLaunchKernelGGL((klhr_iter_kernel<MODEL_FUNNEL, OVERRELAX>), grid, block, lds, s->stream, kp); break;
-        case KLHR_MODEL_ILL_NORMAL: hipLaunchKernelGGL((klhr_iter_kernel<MODEL_ILL_NORMAL, OVERRELAX>), grid, block, lds, s->stream, kp); break;
-        case KLHR_MODEL_GLMM_POISSON: hipLaunchKernelGGL((klhr_iter_kernel<MODEL_GLMM_POISSON, OVERRELAX>), grid, block, lds, s->stream, kp); break;
-        default: hipLaunchKernelGGL((klhr_iter_kernel<MODEL_NORMAL, OVERRELAX>), grid, block, lds, s->stream, kp); break;
-        }
-    }
-}
-
 static int launch_iter(klhr_sampler *s, const KParams &kp_in) {
     KParams kp = kp_in;
     kp.S = s->use_lane ? s->S_lane : s->S;
-    if (s->cfg.overrelaxed) launch_iter_t<true>(s, kp, s->use_lane);
-    else launch_iter_t<false>(s, kp, s->use_lane);
+    const bool o = s->cfg.overrelaxed != 0;
+    if (s->cfg.variant == 1) (o ? launch_hot_v1_o1 : launch_hot_v1_o0)(kp, s->cfg.model_id, s->use_lane, s->stream);
+    else (o ? launch_hot_v0_o1 : launch_hot_v0_o0)(kp, s->cfg.model_id, s->use_lane, s->stream);
     HIPCHECK(s, hipGetLastError());
     return 0;
 }
@@ -567,6 +559,7 @@ static bool field_info(klhr_sampler *s, int field, void **ptr, size_t *bytes) {
     case KLHR_F_ETA: *ptr = k.d_eta; *bytes = C * 32; return true;
     case KLHR_F_DIAG: *ptr = k.d_diag; *bytes = C * KLHR_NDIAG * 8; return true;
     case KLHR_F_STATUS: *ptr = k.status; *bytes = C * 4; return true;
+    case KLHR_F_KSTATE: *ptr = k.kstate; *bytes = C * 32; return true;
     }
     return false;
 }

@@ -34,13 +34,17 @@
 namespace klhr {
 
 enum { PH_DIR = 1, PH_FIT = 2, PH_MH = 4, PH_ADAPT = 8, PH_ALL = 15, PH_KL = 16, PH_LINE = 32 };
+enum { VAR_SINH = 0, VAR_GAUSS = 1 };
+// OnlinePCA's own tolerance: both samplers construct OnlinePCA(D, K=J, l=l) with its default tol = 1e-10
+// (klhr_sinh.py:62, klhr.py:63, onlinepca.py:5), independently of the sampler's `tol`.
+#define PCA_TOL 1e-10
 enum { FLAG_SCALE_DIR_COV = 1, FLAG_EIGEN_ONE = 2, FLAG_DIAG = 4, FLAG_DRAWS = 8, FLAG_OVERRELAXED = 16 };
 
 struct KParams {
-    int C, D, S, ncol, J, K, flags, phases, n_iters;
+    int C, D, S, ncol, J, K, flags, phases, n_iters, variant;   // variant: 0 KLHRSINH (klhr_sinh.py), 1 KLHR (klhr.py)
     ModelData md;
     double tol, scale_clip, initscale, l;
-    double wq[8], asx[8];      // quadrature weights and asinh(node) (nodes themselves are not needed on the device)
+    double xq[8], wq[8], asx[8];   // quadrature nodes, weights, asinh(node)
     double *theta;
     uint64_t *rng;
     double *mean, *cov, *eigvecs, *eigvals, *om_m, *om_v, *omd_m, *omd_v, *pca_v, *acc;
@@ -49,6 +53,7 @@ struct KParams {
     long long *grad_evals;
     int *status;
     double *d_rho, *d_eta, *d_diag;
+    double *kstate;           // C×4 (KLHR variant): Smoother x, Smoother count, current K, moved-in-last-MH-step flag
     double *draws;            // [n_iters][C][D] or nullptr
     long long warmup, windowsize;
     int nclos;
@@ -134,6 +139,41 @@ __device__ inline double overrelaxed_zp(Pcg64 &rng, const double *eta, int K, do
     return sa_T(normcdfinv(up), eta, tol, sc);
 }
 
+// ---- KLHR (klhr.py): Gaussian proposal N(m, s), s = exp(clip(eta1, +-scale_clip))  (klhr.py:81-85,152-174)
+__device__ __forceinline__ double gauss_logq(double x, double m, double s) {
+    const double z = (x - m) / s;
+    return -log(s) - 0.5 * z * z;
+}
+template <bool OVERRELAX>
+__device__ inline double gauss_zp(Pcg64 &rng, const double *eta, int K, double sc) {
+    const double m = eta[0], s = exp(clipc(eta[1], sc));
+    if constexpr (!OVERRELAX) {
+        return __dadd_rn(m, __dmul_rn(s, rng_std_normal(rng)));          // rng.normal(loc=m, scale=s)
+    } else {
+        const double u = normcdf((0.0 - m) / s);
+        int r = 0;
+        for (int k = 0; k < K; k++) r += (pcg_next_double(rng) < u) ? 1 : 0;
+        double up = u;
+        int a = 0, b = 0;
+        if (r > K - r) { a = K - r + 1; b = 2 * r - K; }
+        else if (r < K - r) { a = r + 1; b = K - 2 * r; }
+        if (a > 0) {
+            double ga = 0.0, gb = 0.0;
+            for (int i = 0; i < a; i++) ga -= log(1.0 - pcg_next_double(rng));
+            for (int i = 0; i < b; i++) gb -= log(1.0 - pcg_next_double(rng));
+            const double v = ga / (ga + gb);
+            up = (r > K - r) ? u * v : 1.0 - (1.0 - u) * v;
+        }
+        return m + s * normcdfinv(up);
+    }
+}
+// Smoother.update(d) (smoother.py:10-14) with d = +1 when the chain moved, -1 otherwise (klhr.py:219-221: _msjd stays 0)
+__device__ __forceinline__ void smoother_update(double &x, double &count, bool moved) {
+    count += 1.0;
+    const double kk = pow(count, -0.75);
+    x = kk * (x + (moved ? 1.0 : -1.0)) + (1 - kk) * x;
+}
+
 // log(cosh(a)) from m = exp(-|a|): |a| - ln 2 + log1p(m^2), log1p(u) = 2 atanh(u/(2+u)) by its odd series (s <= 1/3,
 // truncation < 2e-18).  Absolute error ~2e-16, at ~40 instead of ~100 instructions for log(cosh(.)).
 __device__ __forceinline__ double log_cosh_from_exp(double absa, double m) {
@@ -150,10 +190,24 @@ __device__ __forceinline__ double log_cosh_from_exp(double absa, double m) {
     return absa + (lp - 0.6931471805599453094);
 }
 
-template <int MODEL>
+template <int MODEL, int VARIANT>
 __device__ __forceinline__ void eval_objective(const KParams &p, const double2 *TR, int n, const double *xt, double asx_l,
                                                double w_l, int l8, double &f, double *g) {
-    if (n == 4) {
+    if (VARIANT == VAR_GAUSS && n != 1) {
+        // klhr.py:109-124: y_n = s x_n + m, raw gradient, KL = -(sum_n w_n logp_n + eta1)
+        const double s_ = exp(clipc(xt[1], p.scale_clip));
+        const double xn = p.xq[l8];
+        const double t = s_ * xn + xt[0];
+        double logp, gdot;
+        model_eval<MODEL>(p.md, [&](int i, double &xi, double &ri) { double2 v = TR[i]; ri = v.y; xi = fma(t, v.y, v.x); },
+                          INFINITY, NoSink(), logp, gdot);
+        const double wgr = w_l * gdot;
+        const double s0 = grp_sum8(w_l * logp), s1 = grp_sum8(wgr), s2 = grp_sum8(wgr * xn * s_);
+        f = -(s0 + xt[1]);
+        g[0] = -s1;
+        g[1] = -(s2 + 1.0);
+        g[2] = g[3] = 0.0;
+    } else if (n == 4) {
         const double s_ = exp(clipc(xt[1], p.scale_clip)) + p.tol;
         const double d_ = exp(clipc(xt[2], p.scale_clip)) + p.tol;
         const double invd = 1.0 / d_;
@@ -229,7 +283,7 @@ __device__ inline void direction_from_normals(const KParams &p, long long c, dou
             if (j < nc) {
                 double e = evec[i * nc + j];
                 if (pick >= 0) { if (j == pick) m = e; }
-                else m += pj[j] * e;
+                else m += (p.variant == VAR_GAUSS ? ev[j] : pj[j]) * e;      // klhr.py:150 weights by raw eigenvalues
             }
         }
         double r = m + sqrt(cov[i]) * Z[rank[i]];
@@ -273,7 +327,7 @@ __device__ inline void pca_update(const KParams &p, long long c, long long n_new
             double nv = sqrt(s);
             for (int i = 0; i < D; i++) udv += Z[i] * TR[i].y;
             KLHR_WAVE_SYNC();
-            for (int i = l8; i < D; i += 8) TR[i].y = w * TR[i].y + (1 - w) * Z[i] * udv / (nv + p.tol);
+            for (int i = l8; i < D; i += 8) TR[i].y = w * TR[i].y + (1 - w) * Z[i] * udv / (nv + PCA_TOL);
             KLHR_WAVE_SYNC();
             s = 0; udv = 0;
             for (int i = 0; i < D; i++) { double vi = TR[i].y; s += vi * vi; }
@@ -283,7 +337,7 @@ __device__ inline void pca_update(const KParams &p, long long c, long long n_new
             for (int i = l8; i < D; i += 8) {
                 double vi = TR[i].y;
                 V[i * K + col] = vi;
-                Z[i] = Z[i] - udv * vi / (nv * nv + p.tol);
+                Z[i] = Z[i] - udv * vi / (nv * nv + PCA_TOL);
             }
             KLHR_WAVE_SYNC();
         }
@@ -336,7 +390,7 @@ __device__ inline void close_window(const KParams &p, long long c, long long omN
         }
     }
 #pragma unroll
-    for (int j = 0; j < 4; j++) { if (bad) vals[j] = 0.0; vals[j] += p.tol; }
+    for (int j = 0; j < 4; j++) { if (bad) vals[j] = 0.0; vals[j] += PCA_TOL; }
     for (int i = l8; i < D; i += 8) {
 #pragma unroll
         for (int j = 0; j < 4; j++) if (j < K) { evec[i * nc + j] = V[i * K + j] / vals[j]; V[i * K + j] = 0.0; }
@@ -352,7 +406,7 @@ __device__ inline void close_window(const KParams &p, long long c, long long omN
 #pragma clang fp contract(fast)
 
 // ------------------------------------------------------------------------------------------------
-template <int MODEL, bool OVERRELAX>
+template <int MODEL, bool OVERRELAX, int VARIANT>
 #ifdef KLHR_OCTET_LB2
 __global__ __launch_bounds__(64, 2) void klhr_iter_kernel(const KParams p)
 #else
@@ -376,6 +430,9 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
     int cidx = (int)p.counters[c * 4 + 3];
     double acc = p.acc[c];
     long long gevals = p.grad_evals[c];
+    double sm_x = 0, sm_cnt = 0, moved_f = 0;
+    int Kc = p.K;
+    if (VARIANT == VAR_GAUSS) { sm_x = p.kstate[c * 4 + 0]; sm_cnt = p.kstate[c * 4 + 1]; Kc = (int)p.kstate[c * 4 + 2]; moved_f = p.kstate[c * 4 + 3]; }
     const double asx_l = p.asx[l8], w_l = p.wq[l8];
     KLHR_WAVE_SYNC();
 
@@ -429,7 +486,7 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
                     if (opt_cache_hit(o)) {
                         f = o.lf; g[0] = o.lg[0]; g[1] = o.lg[1]; g[2] = o.lg[2]; g[3] = o.lg[3];
                     } else {
-                        eval_objective<MODEL>(p, TR, o.n, o.xt, asx_l, w_l, l8, f, g);
+                        eval_objective<MODEL, VARIANT>(p, TR, o.n, o.xt, asx_l, w_l, l8, f, g);
                         opt_cache_store(o, f, g);
                         dg_pass++;
                     }
@@ -445,15 +502,21 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
                             dg_mode = o.xk[0]; dg_hinv1 = o.H[0]; dg_nfev1 = o.nfev; dg_nit1 = o.k; dg_st1 = o.status; dg_fb = o.fallbacks;
                             double s = o.H[0];
                             s = (s > 0 ? 1.0 : 0.0) * 0.5 * log(s);
-                            // init = rng.normal(size=4) * initscale, then [0], [1] overwritten (klhr_sinh.py:191-193):
-                            // four normals are consumed, the first two discarded (no loop: keeps init[] in registers)
-                            (void)rng_std_normal(rng);
-                            (void)rng_std_normal(rng);
-                            const double n2 = rng_std_normal(rng) * p.initscale;
-                            const double n3 = rng_std_normal(rng) * p.initscale;
-                            double init[4] = {o.xk[0], s, n2, n3};
-                            for (int k = 0; k < 4; k++) dg_init[k] = init[k];
-                            opt_begin(o, 4, init, 1e-3);
+                            if (VARIANT == VAR_GAUSS) {          // klhr.py:134-139: no extra normals, default gtol
+                                double init[4] = {o.xk[0], s, 0.0, 0.0};
+                                for (int k = 0; k < 4; k++) dg_init[k] = init[k];
+                                opt_begin(o, 2, init, 1e-5);
+                            } else {
+                                // init = rng.normal(size=4) * initscale, then [0], [1] overwritten (klhr_sinh.py:191-193):
+                                // four normals are consumed, the first two discarded (no loop: keeps init[] in registers)
+                                (void)rng_std_normal(rng);
+                                (void)rng_std_normal(rng);
+                                const double n2 = rng_std_normal(rng) * p.initscale;
+                                const double n3 = rng_std_normal(rng) * p.initscale;
+                                double init[4] = {o.xk[0], s, n2, n3};
+                                for (int k = 0; k < 4; k++) dg_init[k] = init[k];
+                                opt_begin(o, 4, init, 1e-3);
+                            }
                         } else {
                             gevals += (long long)o.nfev * 8;
                             for (int k = 0; k < 4; k++) eta[k] = o.xk[k];
@@ -476,7 +539,7 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
         // =============================================================== KL / line probes (API + tests)
         if (p.phases & (PH_KL | PH_LINE)) {
             double f, g[4];
-            eval_objective<MODEL>(p, TR, (p.phases & PH_KL) ? 4 : 1, eta, asx_l, w_l, l8, f, g);
+            eval_objective<MODEL, VARIANT>(p, TR, (p.phases & PH_KL) ? (VARIANT == VAR_GAUSS ? 2 : 4) : 1, eta, asx_l, w_l, l8, f, g);
             if (l8 == 0) {
                 double *dd = p.d_diag + c * KLHR_NDIAG;
                 dd[0] = f; dd[1] = g[0]; dd[2] = g[1]; dd[3] = g[2]; dd[4] = g[3];
@@ -488,7 +551,8 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
         if (p.phases & PH_MH) {
             draw += 1;
             double zp;
-            if constexpr (OVERRELAX) zp = overrelaxed_zp(rng, eta, p.K, p.tol, p.scale_clip);
+            if constexpr (VARIANT == VAR_GAUSS) zp = gauss_zp<OVERRELAX>(rng, eta, Kc, p.scale_clip);
+            else if constexpr (OVERRELAX) zp = overrelaxed_zp(rng, eta, p.K, p.tol, p.scale_clip);
             else zp = sa_T(rng_std_normal(rng), eta, p.tol, p.scale_clip);
             double logp, gdot;
             const double t = (l8 == 0) ? zp : 0.0;
@@ -498,18 +562,28 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
             const double lp_c = __shfl(logp, (grp << 3) + 1);
             double r = lp_p;
             r -= lp_c;
-            r += sa_log_q(0.0, eta, p.tol, p.scale_clip);
-            r -= sa_log_q(zp, eta, p.tol, p.scale_clip);
+            if constexpr (VARIANT == VAR_GAUSS) {
+                const double gm = eta[0], gs = exp(clipc(eta[1], p.scale_clip));
+                r += gauss_logq(0.0, gm, gs);
+                r -= gauss_logq(zp, gm, gs);
+            } else {
+                r += sa_log_q(0.0, eta, p.tol, p.scale_clip);
+                r -= sa_log_q(zp, eta, p.tol, p.scale_clip);
+            }
             const double logu = log(rng_uniform(rng));
             const double mn = (r != r) ? r : (r < 0 ? r : 0.0);      // np.minimum(0, r)
             const int a = logu < mn ? 1 : 0;
             const double ad = (double)a, na = (double)(1 - a);
+            double d2 = 0.0;
             for (int i = l8; i < D; i += 8) {
                 double2 v = TR[i];
                 double thp = __dadd_rn(__dmul_rn(zp, v.y), v.x);
-                v.x = __dadd_rn(__dmul_rn(ad, thp), __dmul_rn(na, v.x));     // a*thetap + (1-a)*theta
+                double nx = __dadd_rn(__dmul_rn(ad, thp), __dmul_rn(na, v.x));     // a*thetap + (1-a)*theta
+                d2 += (nx - v.x) * (nx - v.x);
+                v.x = nx;
                 TR[i] = v;
             }
+            if (VARIANT == VAR_GAUSS) moved_f = (sqrt(grp_sum8(d2)) > 0.0) ? 1.0 : 0.0;   // ||theta - prev_theta|| > _msjd = 0
             acc += (ad - acc) / (double)draw;
             dg_zp = zp; dg_r = r; dg_logu = logu; dg_acc = a;
             KLHR_WAVE_SYNC();
@@ -527,15 +601,21 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
                 close_window(p, c, omN, TR, Z, l8);
                 omN = 0;
                 pcan = 0;
+                if (VARIANT == VAR_GAUSS) {      // klhr.py:212-214: K = int(clip(Smoother.optimum(), 1, 50)); reset
+                    Kc = (int)(sm_x < 1.0 ? 1.0 : (sm_x > 50.0 ? 50.0 : sm_x));
+                    sm_x = (double)p.K; sm_cnt = 0.0;
+                }
             } else {
                 omN += 1;
+                if (VARIANT == VAR_GAUSS) smoother_update(sm_x, sm_cnt, moved_f != 0.0);
                 if (p.flags & FLAG_SCALE_DIR_COV) {
                     // _logp_grad(theta): gradient clipped at +-scale_clip feeds the density moments
                     double lp_, gd_;
                     model_eval<MODEL>(p.md, [&](int i, double &xi, double &ri) { double2 v = TR[i]; xi = v.x; ri = 0.0; }, INFINITY,
                                       [&](int i, double gi) { if ((i & 7) == l8) Z[i] = gi; }, lp_, gd_);
                     KLHR_WAVE_SYNC();
-                    om_update_strided(p.omd_m + c * (long long)D, p.omd_v + c * (long long)D, omN, D, l8, TR, Z, true, p.scale_clip);
+                    om_update_strided(p.omd_m + c * (long long)D, p.omd_v + c * (long long)D, omN, D, l8, TR, Z, true,
+                                      VARIANT == VAR_GAUSS ? INFINITY : p.scale_clip);     // klhr.py:216 feeds the raw gradient
                     KLHR_WAVE_SYNC();
                 }
                 om_update_strided(p.om_m + c * (long long)D, p.om_v + c * (long long)D, omN, D, l8, TR, Z, false, 0.0);
@@ -568,6 +648,7 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
         p.counters[c * 4 + 0] = draw; p.counters[c * 4 + 1] = omN; p.counters[c * 4 + 2] = pcan; p.counters[c * 4 + 3] = cidx;
         p.acc[c] = acc;
         p.grad_evals[c] = gevals;
+        if (VARIANT == VAR_GAUSS) { p.kstate[c * 4 + 0] = sm_x; p.kstate[c * 4 + 1] = sm_cnt; p.kstate[c * 4 + 2] = (double)Kc; p.kstate[c * 4 + 3] = moved_f; }
         if ((p.flags & FLAG_DIAG) && !(p.phases & (PH_KL | PH_LINE))) {
             double *dd = p.d_diag + c * KLHR_NDIAG;
             dd[KLHR_D_X0] = dg_x0; dd[KLHR_D_MODE] = dg_mode; dd[KLHR_D_HINV1] = dg_hinv1; dd[KLHR_D_NFEV1] = dg_nfev1;
@@ -626,6 +707,7 @@ __global__ void klhr_logp_kernel(ModelData md, const double *thetas, long long n
     lp_out[k] = lp;
 }
 
+#ifndef KLHR_HOT_TU   // plain (non-template) kernels live in the API translation unit only
 // sinh-arcsinh primitives for n (x, eta) pairs (klhr_sinh.py:112-156,230-240)
 __global__ void klhr_prim_kernel(const double *x, const double *eta, long long n, double tol, double sc, double *out) {
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -645,6 +727,8 @@ __global__ void klhr_prim_kernel(const double *x, const double *eta, long long n
     const double t = tanh(ac);
     o[8] = 0.0; o[9] = -1.0; o[10] = 1 + t * a; o[11] = -t * invd;
 }
+
+#endif  // KLHR_HOT_TU
 
 // MH.draw() (mh.py:18-37), one thread per chain; proposal scratch in p.d_rho (C×D)
 template <int MODEL>
@@ -692,6 +776,7 @@ __global__ void klhr_mh_kernel(const KParams p, double stepsize, int seed_only) 
     p.acc[c] = acc;
 }
 
+#ifndef KLHR_HOT_TU
 // rank permutation of cov after klhr_set_state(KLHR_F_COV)
 __global__ void klhr_rank_kernel(const double *cov, int *rank, int C, int D) {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -791,5 +876,7 @@ __global__ void klhr_pool_apply_kernel(const double *mean_in, const double *cov_
         rank[c * (long long)D + i] = r;
     }
 }
+
+#endif  // KLHR_HOT_TU
 
 }  // namespace klhr

@@ -50,7 +50,7 @@ __device__ inline void lane_direction(const KParams &p, long long c, double2 *TR
             if (j < nc) {
                 double e = evec[i * nc + j];
                 if (pick >= 0) { if (j == pick) m = e; }
-                else m += pj[j] * e;
+                else m += (p.variant == VAR_GAUSS ? ev[j] : pj[j]) * e;      // klhr.py:150
             }
         }
         double r = m + sqrt(cov[i]) * Z[rank[i]];
@@ -89,12 +89,12 @@ __device__ inline void lane_pca_update(const KParams &p, long long c, long long 
             for (int i = 0; i < D; i++) { double vi = V[i * K + col]; s += vi * vi; }
             double nv = sqrt(s);
             for (int i = 0; i < D; i++) udv += Z[i] * V[i * K + col];
-            for (int i = 0; i < D; i++) V[i * K + col] = w * V[i * K + col] + (1 - w) * Z[i] * udv / (nv + p.tol);
+            for (int i = 0; i < D; i++) V[i * K + col] = w * V[i * K + col] + (1 - w) * Z[i] * udv / (nv + PCA_TOL);
             s = 0; udv = 0;
             for (int i = 0; i < D; i++) { double vi = V[i * K + col]; s += vi * vi; }
             nv = sqrt(s);
             for (int i = 0; i < D; i++) udv += Z[i] * V[i * K + col];
-            for (int i = 0; i < D; i++) Z[i] = Z[i] - udv * V[i * K + col] / (nv * nv + p.tol);
+            for (int i = 0; i < D; i++) Z[i] = Z[i] - udv * V[i * K + col] / (nv * nv + PCA_TOL);
         }
     }
 }
@@ -138,7 +138,7 @@ __device__ inline void lane_close_window(const KParams &p, long long c, long lon
         }
     }
 #pragma unroll
-    for (int j = 0; j < 4; j++) { if (bad) vals[j] = 0.0; vals[j] += p.tol; }
+    for (int j = 0; j < 4; j++) { if (bad) vals[j] = 0.0; vals[j] += PCA_TOL; }
     for (int i = 0; i < D; i++) {
 #pragma unroll
         for (int j = 0; j < 4; j++) if (j < K) { evec[i * nc + j] = V[i * K + j] / vals[j]; V[i * K + j] = 0.0; }
@@ -195,6 +195,32 @@ __device__ __forceinline__ void lane_eval_kl(const KParams &p, const double2 *TR
     f = out; g[0] = g0; g[1] = g1; g[2] = g2; g[3] = g3;
 }
 
+// KLHR objective (klhr.py:109-124) for this lane's chain: 8 nodes y_n = s x_n + m, raw gradient
+template <int MODEL>
+__device__ __forceinline__ void lane_eval_kl_gauss(const KParams &p, const double2 *TR, const double *xt, double &f, double *g) {
+    constexpr int NVG = KLHR_NVG;
+    const double s_ = exp(clipc(xt[1], p.scale_clip));
+    double out = 0.0, g0 = 0.0, g1 = 0.0;
+#pragma unroll
+    for (int h = 0; h < 8 / NVG; h++) {
+        double t[NVG], logp[NVG], gdot[NVG];
+#pragma unroll
+        for (int n = 0; n < NVG; n++) t[n] = s_ * p.xq[h * NVG + n] + xt[0];
+        model_eval_nv<MODEL, NVG>(p.md, TR, t, INFINITY, logp, gdot);
+#pragma unroll
+        for (int n = 0; n < NVG; n++) {
+            const double w = p.wq[h * NVG + n];
+            out += w * logp[n];
+            const double wgr = w * gdot[n];
+            g0 += wgr;
+            g1 += wgr * p.xq[h * NVG + n] * s_;
+        }
+    }
+    out += xt[1];
+    g1 += 1;
+    f = -out; g[0] = -g0; g[1] = -g1; g[2] = g[3] = 0.0;
+}
+
 template <int MODEL>
 __device__ __forceinline__ void lane_eval_line(const KParams &p, const double2 *TR, double tv, double &f, double *g) {
     double t[1] = {tv}, logp[1], gdot[1];
@@ -205,7 +231,7 @@ __device__ __forceinline__ void lane_eval_line(const KParams &p, const double2 *
 // ------------------------------------------------------------------------------------------------
 // OVERRELAX is a compile-time switch: the over-relaxed proposal's code (binomial/beta loops, Phi, Phi^-1) would otherwise
 // sit in the register allocation of every launch (measured: +1.5 KB scratch per lane, -8 % throughput).
-template <int MODEL, bool OVERRELAX>
+template <int MODEL, bool OVERRELAX, int VARIANT>
 __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x & 63;
@@ -233,6 +259,9 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
     long long draw = 0, omN = 0, pcan = 0, gevals = 0;
     int cidx = 0;
     double acc = 0;
+    double sm_x = 0, sm_cnt = 0, moved_f = 0;
+    int Kc = p.K;
+    if (VARIANT == VAR_GAUSS && active) { sm_x = p.kstate[c * 4 + 0]; sm_cnt = p.kstate[c * 4 + 1]; Kc = (int)p.kstate[c * 4 + 2]; moved_f = p.kstate[c * 4 + 3]; }
     if (active) {
         rng.sh = p.rng[c * 4 + 0]; rng.sl = p.rng[c * 4 + 1]; rng.ih = p.rng[c * 4 + 2]; rng.il = p.rng[c * 4 + 3];
         draw = p.counters[c * 4 + 0]; omN = p.counters[c * 4 + 1]; pcan = p.counters[c * 4 + 2]; cidx = (int)p.counters[c * 4 + 3];
@@ -274,10 +303,12 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
                 double x0v[4] = {0, 0, 0, 0};
                 if (active) {
                     x0v[0] = rng_std_normal(rng) * p.initscale;
-                    (void)rng_std_normal(rng);
-                    (void)rng_std_normal(rng);
-                    fit_n2 = rng_std_normal(rng) * p.initscale;
-                    fit_n3 = rng_std_normal(rng) * p.initscale;
+                    if (VARIANT == VAR_SINH) {               // klhr.py's fit draws no further normals (klhr.py:134-139)
+                        (void)rng_std_normal(rng);
+                        (void)rng_std_normal(rng);
+                        fit_n2 = rng_std_normal(rng) * p.initscale;
+                        fit_n3 = rng_std_normal(rng) * p.initscale;
+                    }
                 }
                 if (diag && active) dd[KLHR_D_X0] = x0v[0];
                 opt_begin(o, 1, x0v, 1e-5);
@@ -288,9 +319,12 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
                 double f = 0, g[4] = {0, 0, 0, 0};
                 const bool hit = !done && opt_cache_hit(o);
                 const bool ev1 = !done && !hit && o.n == 1;
-                const bool ev4 = !done && !hit && o.n == 4;
+                const bool ev4 = !done && !hit && o.n != 1;
                 if (ev1) lane_eval_line<MODEL>(p, TR, o.xt[0], f, g);
-                if (ev4) lane_eval_kl<MODEL>(p, TR, o.xt, f, g);
+                if (ev4) {
+                    if constexpr (VARIANT == VAR_GAUSS) lane_eval_kl_gauss<MODEL>(p, TR, o.xt, f, g);
+                    else lane_eval_kl<MODEL>(p, TR, o.xt, f, g);
+                }
                 if (!done) {
                     if (hit) { f = o.lf; g[0] = o.lg[0]; g[1] = o.lg[1]; g[2] = o.lg[2]; g[3] = o.lg[3]; }
                     else { opt_cache_store(o, f, g); npass++; }
@@ -306,7 +340,8 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
                             s = (s > 0 ? 1.0 : 0.0) * 0.5 * log(s);
                             double init[4] = {o.xk[0], s, fit_n2, fit_n3};
                             if (diag) { dd[KLHR_D_INIT0] = init[0]; dd[KLHR_D_INIT1] = init[1]; dd[KLHR_D_INIT2] = init[2]; dd[KLHR_D_INIT3] = init[3]; }
-                            opt_begin(o, 4, init, 1e-3);
+                            if (VARIANT == VAR_GAUSS) opt_begin(o, 2, init, 1e-5);      // klhr.py:136-139: default gtol
+                            else opt_begin(o, 4, init, 1e-3);
                         } else {
                             gevals += (long long)o.nfev * 8;
                             for (int k = 0; k < 4; k++) eta[k] = o.xk[k];
@@ -330,8 +365,10 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
         // =============================================================== KL / line probes
         if ((p.phases & (PH_KL | PH_LINE)) && active) {
             double f, g[4];
-            if (p.phases & PH_KL) lane_eval_kl<MODEL>(p, TR, eta, f, g);
-            else lane_eval_line<MODEL>(p, TR, eta[0], f, g);
+            if (p.phases & PH_KL) {
+                if constexpr (VARIANT == VAR_GAUSS) lane_eval_kl_gauss<MODEL>(p, TR, eta, f, g);
+                else lane_eval_kl<MODEL>(p, TR, eta, f, g);
+            } else lane_eval_line<MODEL>(p, TR, eta[0], f, g);
             double *dp = p.d_diag + c * KLHR_NDIAG;
             dp[0] = f; dp[1] = g[0]; dp[2] = g[1]; dp[3] = g[2]; dp[4] = g[3];
         }
@@ -340,24 +377,35 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
         if ((p.phases & PH_MH) && active) {
             draw += 1;
             double zp;
-            if constexpr (OVERRELAX) zp = overrelaxed_zp(rng, eta, p.K, p.tol, p.scale_clip);
+            if constexpr (VARIANT == VAR_GAUSS) zp = gauss_zp<OVERRELAX>(rng, eta, Kc, p.scale_clip);
+            else if constexpr (OVERRELAX) zp = overrelaxed_zp(rng, eta, p.K, p.tol, p.scale_clip);
             else zp = sa_T(rng_std_normal(rng), eta, p.tol, p.scale_clip);
             double t2[2] = {zp, 0.0}, lp2[2], gd2[2];
             model_eval_nv<MODEL, 2>(p.md, TR, t2, INFINITY, lp2, gd2);
             double r = lp2[0];
             r -= lp2[1];
-            r += sa_log_q(0.0, eta, p.tol, p.scale_clip);
-            r -= sa_log_q(zp, eta, p.tol, p.scale_clip);
+            if constexpr (VARIANT == VAR_GAUSS) {
+                const double gm = eta[0], gs = exp(clipc(eta[1], p.scale_clip));
+                r += gauss_logq(0.0, gm, gs);
+                r -= gauss_logq(zp, gm, gs);
+            } else {
+                r += sa_log_q(0.0, eta, p.tol, p.scale_clip);
+                r -= sa_log_q(zp, eta, p.tol, p.scale_clip);
+            }
             const double logu = log(rng_uniform(rng));
             const double mn = (r != r) ? r : (r < 0 ? r : 0.0);
             const int a = logu < mn ? 1 : 0;
             const double ad = (double)a, na = (double)(1 - a);
+            double d2 = 0.0;
             for (int i = 0; i < D; i++) {
                 double2 v = TR[i];
                 double thp = __dadd_rn(__dmul_rn(zp, v.y), v.x);
-                v.x = __dadd_rn(__dmul_rn(ad, thp), __dmul_rn(na, v.x));
+                double nx = __dadd_rn(__dmul_rn(ad, thp), __dmul_rn(na, v.x));
+                if (VARIANT == VAR_GAUSS) d2 += (nx - v.x) * (nx - v.x);
+                v.x = nx;
                 TR[i] = v;
             }
+            if (VARIANT == VAR_GAUSS) moved_f = (sqrt(d2) > 0.0) ? 1.0 : 0.0;
             acc += (ad - acc) / (double)draw;
             if (diag) { dd[KLHR_D_ZP] = zp; dd[KLHR_D_R] = r; dd[KLHR_D_LOGU] = logu; dd[KLHR_D_ACCEPT] = a; }
         }
@@ -373,13 +421,19 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
                 lane_close_window(p, c, omN, Z);
                 omN = 0;
                 pcan = 0;
+                if (VARIANT == VAR_GAUSS) {      // klhr.py:212-214
+                    Kc = (int)(sm_x < 1.0 ? 1.0 : (sm_x > 50.0 ? 50.0 : sm_x));
+                    sm_x = (double)p.K; sm_cnt = 0.0;
+                }
             } else {
                 omN += 1;
+                if (VARIANT == VAR_GAUSS) smoother_update(sm_x, sm_cnt, moved_f != 0.0);
                 if (p.flags & FLAG_SCALE_DIR_COV) {
                     double lp_, gd_;
                     model_eval<MODEL>(p.md, [&](int i, double &xi, double &ri) { xi = TR[i].x; ri = 0.0; }, INFINITY,
                                       [&](int i, double gi) { Z[i] = gi; }, lp_, gd_);
-                    lane_om_update(p.omd_m + c * (long long)D, p.omd_v + c * (long long)D, omN, D, TR, Z, true, p.scale_clip);
+                    lane_om_update(p.omd_m + c * (long long)D, p.omd_v + c * (long long)D, omN, D, TR, Z, true,
+                                   VARIANT == VAR_GAUSS ? INFINITY : p.scale_clip);
                 }
                 lane_om_update(p.om_m + c * (long long)D, p.om_v + c * (long long)D, omN, D, TR, Z, false, 0.0);
                 const double *mean = p.mean + c * (long long)D;
@@ -424,6 +478,7 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
         p.counters[c * 4 + 0] = draw; p.counters[c * 4 + 1] = omN; p.counters[c * 4 + 2] = pcan; p.counters[c * 4 + 3] = cidx;
         p.acc[c] = acc;
         p.grad_evals[c] = gevals;
+        if (VARIANT == VAR_GAUSS) { p.kstate[c * 4 + 0] = sm_x; p.kstate[c * 4 + 1] = sm_cnt; p.kstate[c * 4 + 2] = (double)Kc; p.kstate[c * 4 + 3] = moved_f; }
     }
 }
 

@@ -10,6 +10,7 @@ import click
 import numpy as np
 
 from .bsmodel import BSModel
+from .klhr import KLHR
 from .klhr_sinh import KLHRSINH
 from .mh import MH
 from .onlinemoments import OnlineMoments
@@ -41,12 +42,13 @@ def running_rmse(draws):
 @click.option("--no-plots", is_flag=True)
 @click.argument("algorithm", type=str)
 def main(M, warmup, verbose, scale_dir_cov, overrelaxed, eigen_method_one, seed, outdir, no_plots, algorithm):
-    if algorithm != "klhr_sinh":
+    if algorithm not in ("klhr_sinh", "klhr"):
         print(f"Unknown algorithm {algorithm}")
-        print("Available algorithms on the GPU path: klhr_sinh")
+        print("Available algorithms on the GPU path: klhr, klhr_sinh")
         sys.exit(0)
+    Sampler = KLHRSINH if algorithm == "klhr_sinh" else KLHR
     bs_model = BSModel(stan_file=STAN / "normal.stan", data_file=STAN / "normal.json")
-    algo = KLHRSINH(bs_model, warmup=warmup, scale_dir_cov=scale_dir_cov, overrelaxed=overrelaxed,
+    algo = Sampler(bs_model, warmup=warmup, scale_dir_cov=scale_dir_cov, overrelaxed=overrelaxed,
                     eigen_method_one=eigen_method_one, seed=seed)
     mh = MH(bs_model, 0.09, seed=None if seed is None else seed + 1)
     draws = algo.sample(M)                       # row 0 = initial point (mcmc.py:34)

@@ -10,6 +10,7 @@ import click
 import numpy as np
 
 from .bsmodel import BSModel
+from .klhr import KLHR
 from .klhr_sinh import KLHRSINH
 
 STAN = Path(__file__).resolve().parent / "stan"
@@ -28,12 +29,13 @@ STAN = Path(__file__).resolve().parent / "stan"
 @click.option("--no-plots", is_flag=True)
 @click.argument("algorithm", type=str)
 def main(M, warmup, verbose, scale_dir_cov, overrelaxed, eigen_method_one, chains, seed, outdir, no_plots, algorithm):
-    if algorithm != "klhr_sinh":
+    if algorithm not in ("klhr_sinh", "klhr"):
         print(f"Unknown algorithm {algorithm}")
-        print("Available algorithms on the GPU path: klhr_sinh")
+        print("Available algorithms on the GPU path: klhr, klhr_sinh")
         sys.exit(0)
+    Sampler = KLHRSINH if algorithm == "klhr_sinh" else KLHR
     bs_model = BSModel(stan_file=STAN / "funnel.stan", data_file=STAN / "funnel.json")
-    algo = KLHRSINH(bs_model, warmup=warmup, scale_dir_cov=scale_dir_cov, overrelaxed=overrelaxed,
+    algo = Sampler(bs_model, warmup=warmup, scale_dir_cov=scale_dir_cov, overrelaxed=overrelaxed,
                     eigen_method_one=eigen_method_one, chains=chains, seed=seed)
     thetas = algo.draws(M)                      # (M, chains, D): M draws, no initial point (experiment_funnel.py:49-52)
     if verbose:

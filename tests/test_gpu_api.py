@@ -209,3 +209,22 @@ def test_pooled_full_covariance_single_rank():
     assert abs(abs(evec[0][:, 0] @ V[:, -1]) - 1) < 1e-8
     sh.advance(60)                     # keeps sampling through the second closure with pooled directions
     assert np.isfinite(s.get("theta")).all()
+
+
+def test_klhr_class_is_the_reference_chain():
+    from klhr_amd import KLHR
+    g = golden("g11_klhr_public_api.npz")
+    algo = KLHR(funnel_model(), seed=0, warmup=100)        # klhr.py defaults: eigen_method_one=True, overrelaxed=False
+    th = np.array([algo.draw() for _ in range(50)])
+    assert np.abs(th - g["s0_thetas"][:50]).max() < 1e-9
+    more = algo.draws(70)
+    assert algo.K == int(g["s0_K"][0])
+    assert np.isfinite(more).all() and algo.acceptance_probability.shape == (1,)
+    rho = algo._random_direction()
+    eta = algo.fit(rho)
+    assert eta.shape == (2,)
+    v, grad = algo.KL(eta, rho)
+    assert np.max(np.abs(grad)) < 1e-4                     # stage-2 BFGS runs to the default gtol = 1e-5 (klhr.py:136-139)
+    many = KLHR(funnel_model(), seed=3, warmup=100, chains=300, overrelaxed=True)
+    many.draws(150)
+    assert many.K.shape == (300,) and many.K.min() >= 1 and many.K.max() <= 50

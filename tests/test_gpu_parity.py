@@ -298,3 +298,114 @@ def test_overrelaxed_proposal_vs_oracle(oracle):
             assert np.allclose(th[m], o.get("theta"), rtol=1e-9, atol=1e-10)
         n_atom += abs(od["zp"]) < 1e-9
     assert 0 < n_atom < M          # both the u' = u branch and the beta branches were exercised
+
+
+G11 = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "g11_klhr_*_w*.npz")))
+
+
+@pytest.mark.parametrize("fn", G11)
+def test_klhr_gaussian_variant_vs_oracle(oracle, fn):
+    """the Gaussian-proposal sibling KLHR (klhr.py).  Every record of a reference trace becomes one GPU
+    chain; direction, fit, MH step and closure-or-update (incl. the Smoother-driven K) are compared with the oracle."""
+    parts = fn[len("g11_klhr_"):-4].split("_")
+    name = parts[0]
+    flags = {"eigen_method_one": False} if parts[-1] == "m2" else {}
+    g = golden(fn)
+    stem, data = model_spec(name)
+    M, warmup, seed = min(int(g["M"][0]), 300), int(g["warmup"][0]), int(g["seed"][0])
+    # ---- oracle pass (teacher-forced on the reference's thetas), snapshotting the state before every draw
+    o = oracle.KLHRChain(stem, data, seed=seed, warmup=warmup, **flags)
+    J = o.J
+    fields = ["mean", "cov", "eigvecs", "eigvals", "om_m", "om_v", "pca_v"]
+    before = {f: [] for f in fields}
+    after = {f: [] for f in fields}
+    cnt_b, cnt_a, ks_b, ks_a = [], [], [], []
+    R = dict(rho=[], eta=[], diag=[], rng_dir=[], rng_fit=[], theta_mh=[], diag_mh=[], rng_mh=[])
+    L = oracle.lib()
+    for m in range(M):
+        for f in fields:
+            before[f].append(o.get(f).copy())
+        cnt_b.append([m, o.get("om_N"), o.get("pca_n"), o.get("cidx")])
+        o.set("theta", g["theta_before"][m]); o.set("rng", g["state_before"][m])
+        R["rho"].append(o.random_direction()); R["rng_dir"].append(o.get("rng"))
+        R["eta"].append(o.fit(g["rho"][m])); R["diag"].append(o.get("diag")); R["rng_fit"].append(o.get("rng"))
+        o.set("draw", m)
+        o.metropolis(np.concatenate([g["eta"][m], [0, 0]]), g["rho"][m])
+        R["theta_mh"].append(o.get("theta")); R["diag_mh"].append(o.get("diag")); R["rng_mh"].append(o.get("rng"))
+        o.set("theta", g["theta_after"][m])
+        o.adapt()
+        for f in fields:
+            after[f].append(o.get(f).copy())
+        cnt_a.append([m + 1, o.get("om_N"), o.get("pca_n"), o.get("cidx")])
+        ks_a.append(L.klhr_oracle_get_K(o._h))
+    # ---- device
+    kw = dict(tol=1e-12, scale_clip=600, overrelaxed=False, eigen_method_one=flags.get("eigen_method_one", True), J=J, variant=1)
+    s = make_sampler(stem, data, M, warmup=warmup, **kw)
+    s.set("theta", g["theta_before"][:M]); s.set("rng", g["state_before"][:M])
+    for f in fields:
+        s.set(f, np.array(before[f]))
+    s.set("counters", np.array(cnt_b, dtype=np.int64))
+    rho = s.random_direction()
+    assert np.array_equal(s.get("rng"), np.array(R["rng_dir"]))
+    assert np.array_equal(rho, np.array(R["rho"])), np.abs(rho - np.array(R["rho"])).max()
+    eta = s.fit(g["rho"][:M])
+    assert np.array_equal(s.get("rng"), np.array(R["rng_fit"]))          # exactly one normal consumed (klhr.py:128)
+    d = s.get("diag")
+    from klhr_amd._lib import DIAG_COLS as DC
+    col = {k: i for i, k in enumerate(DC)}
+    o_nfev1 = np.array([x["nfev1"] for x in R["diag"]]); o_nfev2 = np.array([x["nfev2"] for x in R["diag"]])
+    o_st2 = np.array([x["status2"] for x in R["diag"]])
+    same = (d[:, col["nfev1"]] == o_nfev1) & (d[:, col["nfev2"]] == o_nfev2)
+    conv = o_st2 == 0
+    assert (same & conv).sum() >= 0.98 * conv.sum(), ((same & conv).sum(), conv.sum())
+    oe = np.array(R["eta"])
+    err = np.abs(eta[:, :2] - oe[:, :2]) / (1 + np.abs(oe[:, :2]))
+    assert np.all(err[same & conv] < 2e-6), err[same & conv].max()
+    assert np.all(eta[:, 2:] == 0)
+    # MH step from the reference's eta
+    cb = np.array(cnt_b, dtype=np.int64)
+    s.set("counters", cb)
+    e4 = np.zeros((M, 4)); e4[:, :2] = g["eta"][:M]
+    s.metropolis(e4, g["rho"][:M])
+    d = s.get("diag")
+    assert np.array_equal(s.get("rng"), np.array(R["rng_mh"]))
+    o_zp = np.array([x["zp"] for x in R["diag_mh"]]); o_r = np.array([x["r"] for x in R["diag_mh"]])
+    o_logu = np.array([x["logu"] for x in R["diag_mh"]]); o_acc = np.array([x["accept"] for x in R["diag_mh"]])
+    assert np.all(np.abs(d[:, col["zp"]] - o_zp) <= 1e-12 * (1 + np.abs(o_zp)))
+    assert np.all(np.abs(d[:, col["r"]] - o_r) <= 1e-9 * (1 + np.abs(o_r)))
+    clear = np.abs(o_logu - np.minimum(0.0, o_r)) > 1e-8
+    assert np.array_equal(d[clear, col["accept"]], o_acc[clear])
+    # closure-or-update from the reference's theta: bit-exact, and K follows the Smoother (klhr.py:212-221)
+    moved = np.any(s.get("theta") != g["theta_before"][:M], axis=1)
+    s.set("theta", g["theta_after"][:M])
+    cb2 = cb.copy(); cb2[:, 0] += 1
+    s.set("counters", cb2)
+    # Smoother state before each record comes from the oracle's run: rebuild it from the accept history
+    ks = np.zeros((M, 4)); x, cntr, K = 10.0, 0.0, 10
+    closures = set([50, 100])
+    for m in range(M):
+        ks[m] = [x, cntr, K, float(bool(g["accept"][m]) and np.any(g["theta_after"][m] != g["theta_before"][m]))]
+        if (m + 1) in closures:
+            K = int(min(max(x, 1.0), 50.0)); x, cntr = 10.0, 0.0
+        else:
+            cntr += 1.0; kk = cntr ** -0.75
+            x = kk * (x + (1.0 if ks[m][3] else -1.0)) + (1 - kk) * x
+    s.set("kstate", ks)
+    s.adapt()
+    assert np.array_equal(s.get("counters"), np.array(cnt_a, dtype=np.int64))
+    for f in fields:
+        assert np.array_equal(s.get(f), np.array(after[f])), f
+    assert np.array_equal(s.get("kstate")[:, 2].astype(int), np.array(ks_a)), "K after adapt"
+    assert np.array_equal(np.array(ks_a), g["K"][:M])
+
+
+def test_klhr_free_running_vs_reference():
+    g = golden("g11_klhr_funnel10_s0_w100.npz")
+    stem, data = model_spec("funnel10")
+    s = make_sampler(stem, data, 1, warmup=100, tol=1e-12, scale_clip=600, eigen_method_one=True, J=2, variant=1)
+    s.seed(np.array([0], dtype=np.uint64))
+    s.step(120, record_draws=True)
+    dr = s.draws(0, 120)[:, 0]
+    err = np.abs(dr - g["theta_after"][:120]).max(axis=1)
+    assert err[:50].max() < 1e-9
+    assert int(s.get("kstate")[0, 2]) == g["K"][119]
