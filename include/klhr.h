@@ -65,7 +65,8 @@ typedef struct klhr_config {
                                                               * chain's own PCG64 stream (the reference uses SciPy's unseeded
                                                               * global RNG there: distribution-exact, not stream-exact) */
     int32_t variant;           /* 0: KLHRSINH, 4-parameter sinh-arcsinh proposal (klhr_sinh.py)
-                                * 1: KLHR, 2-parameter Gaussian proposal (klhr.py:15-223); eta is then (m, log s, 0, 0) */
+                                * 1: KLHR, 2-parameter Gaussian proposal (klhr.py:15-223); eta is then (m, log s, 0, 0)
+                                * 2: SUBKLHRSINH, 3-parameter sinh-arcsinh, d == 1 (sub_klhr_sinh.py); eta = (m, log s, e, 0) */
     const double *quad_x;      /* N probabilists' Gauss-Hermite nodes   (klhr_sinh.py:44-47) */
     const double *quad_w;      /* N weights                                                  */
     const double *quad_asinh_x;/* N values asinh(x_n) (host-computed, np.arcsinh)            */

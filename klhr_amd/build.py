@@ -1,6 +1,6 @@
 """Build libklhr_hip.so for gfx950 in-tree (klhr_amd/lib/).  `python -m klhr_amd.build [--force] [-v]`
 
-Five translation units are compiled in parallel and linked: klhr_api.hip (C ABI + small kernels) and klhr_hot.hip four
+Seven translation units are compiled in parallel and linked: klhr_api.hip (C ABI + small kernels) and klhr_hot.hip six
 times, once per (sampler variant, over-relaxation) pair — see the comment at the top of klhr_hot.hip."""
 import os
 import subprocess
@@ -29,7 +29,7 @@ def build(force=False, verbose=False, extra=()):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = FLAGS + list(extra) + (["-Rpass-analysis=kernel-resource-usage"] if verbose else [])
     jobs = [("api.o", ["-c", os.path.join(SRC, "klhr_api.hip")])]
-    for v in (0, 1):
+    for v in (0, 1, 2):
         for o in (0, 1):
             jobs.append((f"hot_v{v}_o{o}.o", ["-c", os.path.join(SRC, "klhr_hot.hip"), f"-DKLHR_VARIANT={v}", f"-DKLHR_OVERRELAX={o}"]))
     procs = []

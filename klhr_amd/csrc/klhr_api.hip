@@ -19,6 +19,8 @@ void launch_hot_v0_o0(const KParams &, int, bool, hipStream_t);
 void launch_hot_v0_o1(const KParams &, int, bool, hipStream_t);
 void launch_hot_v1_o0(const KParams &, int, bool, hipStream_t);
 void launch_hot_v1_o1(const KParams &, int, bool, hipStream_t);
+void launch_hot_v2_o0(const KParams &, int, bool, hipStream_t);
+void launch_hot_v2_o1(const KParams &, int, bool, hipStream_t);
 }  // namespace klhr
 
 using namespace klhr;
@@ -184,7 +186,7 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
     if (cfg->J < 1 || cfg->J > 3) return fail("klhr_create: need 1 <= J <= 3");
     if (cfg->overrelaxed && (cfg->K < 1 || cfg->K > 64)) return fail("klhr_create: overrelaxed needs 1 <= K <= 64");
     if (cfg->chains < 1) return fail("klhr_create: chains < 1");
-    if (cfg->variant != 0 && cfg->variant != 1) return fail("klhr_create: variant must be 0 (KLHRSINH) or 1 (KLHR)");
+    if (cfg->variant < 0 || cfg->variant > 2) return fail("klhr_create: variant must be 0 (KLHRSINH), 1 (KLHR) or 2 (SUBKLHRSINH)");
     if (!model_data || n_model_data < 1 || !cfg->quad_x || !cfg->quad_w || !cfg->quad_asinh_x) return fail("klhr_create: null data");
     int D = 0, n = 0;
     std::vector<double> aux;
@@ -243,7 +245,7 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
     k.flags = (cfg->scale_dir_cov ? FLAG_SCALE_DIR_COV : 0) | (cfg->eigen_method_one ? FLAG_EIGEN_ONE : 0) |
               (cfg->overrelaxed ? FLAG_OVERRELAXED : 0);
     k.K = cfg->K;
-    k.tol = cfg->tol; k.scale_clip = cfg->scale_clip; k.initscale = cfg->initscale; k.l = cfg->l;
+    k.tol = cfg->tol; k.scale_clip = cfg->scale_clip; k.grad_clip = cfg->grad_clip; k.initscale = cfg->initscale; k.l = cfg->l;
     for (int i = 0; i < 8; i++) { k.xq[i] = cfg->quad_x[i]; k.wq[i] = cfg->quad_w[i]; k.asx[i] = cfg->quad_asinh_x[i]; }
     k.variant = cfg->variant;
     TRY(dalloc(s, &s->d_aux, aux.size()));
@@ -298,7 +300,8 @@ static int launch_iter(klhr_sampler *s, const KParams &kp_in) {
     KParams kp = kp_in;
     kp.S = s->use_lane ? s->S_lane : s->S;
     const bool o = s->cfg.overrelaxed != 0;
-    if (s->cfg.variant == 1) (o ? launch_hot_v1_o1 : launch_hot_v1_o0)(kp, s->cfg.model_id, s->use_lane, s->stream);
+    if (s->cfg.variant == 2) (o ? launch_hot_v2_o1 : launch_hot_v2_o0)(kp, s->cfg.model_id, s->use_lane, s->stream);
+    else if (s->cfg.variant == 1) (o ? launch_hot_v1_o1 : launch_hot_v1_o0)(kp, s->cfg.model_id, s->use_lane, s->stream);
     else (o ? launch_hot_v0_o1 : launch_hot_v0_o0)(kp, s->cfg.model_id, s->use_lane, s->stream);
     HIPCHECK(s, hipGetLastError());
     return 0;
@@ -527,7 +530,7 @@ extern "C" int klhr_primitives(klhr_sampler *s, const double *x, const double *e
     if (!rc) rc = h2d(s, d_e, eta, (size_t)n * 32);
     if (!rc) {
         const int bs = 64;
-        hipLaunchKernelGGL(klhr_prim_kernel, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, s->stream, d_x, d_e, (long long)n, s->cfg.tol, s->cfg.scale_clip, d_o);
+        hipLaunchKernelGGL(klhr_prim_kernel, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, s->stream, d_x, d_e, (long long)n, s->cfg.tol, s->cfg.scale_clip, d_o, s->cfg.variant == 2 ? 1 : 0);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { s->err = hipGetErrorString(e); rc = KLHR_ERR_HIP; }
     }

@@ -1,5 +1,5 @@
 // klhr_hot.hip — one translation unit per (sampler variant, over-relaxation) pair of the hot-path kernels.
-// Compiled four times by klhr_amd/build.py with -DKLHR_VARIANT={0,1} -DKLHR_OVERRELAX={0,1}: the variants are
+// Compiled six times by klhr_amd/build.py with -DKLHR_VARIANT={0,1,2} -DKLHR_OVERRELAX={0,1}: the variants are
 // compile-time template arguments so that the code of one never weighs on the register allocation of another
 // (measured: a runtime-flagged over-relaxed branch cost the default path 8 % and 1.5 KB of scratch per lane).
 #define KLHR_HOT_TU 1
@@ -7,7 +7,7 @@
 #include "klhr_lane_kernel.hpp"
 
 #ifndef KLHR_VARIANT
-#error "compile with -DKLHR_VARIANT=0|1 -DKLHR_OVERRELAX=0|1"
+#error "compile with -DKLHR_VARIANT=0|1|2 -DKLHR_OVERRELAX=0|1"
 #endif
 #define KLHR_CAT_(a, b, c, d) a##b##c##d
 #define KLHR_CAT(a, b, c, d) KLHR_CAT_(a, b, c, d)

@@ -34,7 +34,7 @@
 namespace klhr {
 
 enum { PH_DIR = 1, PH_FIT = 2, PH_MH = 4, PH_ADAPT = 8, PH_ALL = 15, PH_KL = 16, PH_LINE = 32 };
-enum { VAR_SINH = 0, VAR_GAUSS = 1 };
+enum { VAR_SINH = 0, VAR_GAUSS = 1, VAR_SUB = 2 };   // klhr_sinh.py / klhr.py / sub_klhr_sinh.py
 // OnlinePCA's own tolerance: both samplers construct OnlinePCA(D, K=J, l=l) with its default tol = 1e-10
 // (klhr_sinh.py:62, klhr.py:63, onlinepca.py:5), independently of the sampler's `tol`.
 #define PCA_TOL 1e-10
@@ -43,7 +43,7 @@ enum { FLAG_SCALE_DIR_COV = 1, FLAG_EIGEN_ONE = 2, FLAG_DIAG = 4, FLAG_DRAWS = 8
 struct KParams {
     int C, D, S, ncol, J, K, flags, phases, n_iters, variant;   // variant: 0 KLHRSINH (klhr_sinh.py), 1 KLHR (klhr.py)
     ModelData md;
-    double tol, scale_clip, initscale, l;
+    double tol, scale_clip, grad_clip, initscale, l;
     double xq[8], wq[8], asx[8];   // quadrature nodes, weights, asinh(node)
     double *theta;
     uint64_t *rng;
@@ -78,35 +78,38 @@ __device__ __forceinline__ double grp_sum8(double v) {
 }
 
 // sinh-arcsinh helpers (klhr_sinh.py:78-84): s = exp(clip(eta1)) + tol, d = exp(clip(eta2)) + tol
-__device__ __forceinline__ void sa_unpack(const double *eta, double tol, double sc, double &m, double &s, double &d, double &e) {
+// sub == true: SUBKLHRSINH's 3-parameter form, d == 1 and e = eta[2] (sub_klhr_sinh.py:92-97)
+__device__ __forceinline__ void sa_unpack(const double *eta, double tol, double sc, double &m, double &s, double &d, double &e,
+                                          bool sub = false) {
     m = eta[0];
     s = exp(clipc(eta[1], sc)) + tol;
+    if (sub) { d = 1.0; e = eta[2]; return; }
     d = exp(clipc(eta[2], sc)) + tol;
     e = eta[3];
 }
 // klhr_sinh.py:112-114
-__device__ inline double sa_T(double x, const double *eta, double tol, double sc) {
+__device__ inline double sa_T(double x, const double *eta, double tol, double sc, bool sub = false) {
     double m, s, d, e;
-    sa_unpack(eta, tol, sc, m, s, d, e);
+    sa_unpack(eta, tol, sc, m, s, d, e, sub);
     return __dadd_rn(m, __dmul_rn(s, sinh(clipc((asinh(x) + e) / d, sc))));
 }
 // klhr_sinh.py:126-129
-__device__ inline double sa_T_inv(double x, const double *eta, double tol, double sc) {
+__device__ inline double sa_T_inv(double x, const double *eta, double tol, double sc, bool sub = false) {
     double m, s, d, e;
-    sa_unpack(eta, tol, sc, m, s, d, e);
+    sa_unpack(eta, tol, sc, m, s, d, e, sub);
     double z = (x - m) / s;
     return sinh(clipc(d * asinh(z) - e, sc));
 }
 // klhr_sinh.py:230-240
-__device__ inline double sa_log_q(double x, const double *eta, double tol, double sc) {
+__device__ inline double sa_log_q(double x, const double *eta, double tol, double sc, bool sub = false) {
     double m, s, d, e;
-    sa_unpack(eta, tol, sc, m, s, d, e);
+    sa_unpack(eta, tol, sc, m, s, d, e, sub);
     double z = (x - m) / s;
     double u = clipc(d * asinh(z) - e, sc);
     double ti = sinh(u);
     double ld = -0.5 * ti * ti;
     ld += log(cosh(u));
-    ld += eta[2] - eta[1];
+    if (sub) ld -= eta[1]; else ld += eta[2] - eta[1];
     ld -= 0.5 * log1p(z * z);
     return ld;
 }
@@ -121,8 +124,8 @@ __device__ inline double sa_log_q(double x, const double *eta, double tol, doubl
 // here they come from the chain's own PCG64 stream with a fixed consumption (documented in DESIGN.md §2, row a13):
 //   K uniforms for the binomial (count of U_k < u), then a + b uniforms for Beta(a, b) = Ga / (Ga + Gb) with
 //   Ga = -sum log(1 - U_i) over a uniforms (integer-shape gamma).  Distributions are exactly those of scipy.stats.
-__device__ inline double overrelaxed_zp(Pcg64 &rng, const double *eta, int K, double tol, double sc) {
-    const double u = normcdf(sa_T_inv(0.0, eta, tol, sc));
+__device__ inline double overrelaxed_zp(Pcg64 &rng, const double *eta, int K, double tol, double sc, bool sub = false) {
+    const double u = normcdf(sa_T_inv(0.0, eta, tol, sc, sub));
     int r = 0;
     for (int k = 0; k < K; k++) r += (pcg_next_double(rng) < u) ? 1 : 0;
     double up = u;
@@ -136,7 +139,7 @@ __device__ inline double overrelaxed_zp(Pcg64 &rng, const double *eta, int K, do
         const double v = ga / (ga + gb);
         up = (r > K - r) ? u * v : 1.0 - (1.0 - u) * v;
     }
-    return sa_T(normcdfinv(up), eta, tol, sc);
+    return sa_T(normcdfinv(up), eta, tol, sc, sub);
 }
 
 // ---- KLHR (klhr.py): Gaussian proposal N(m, s), s = exp(clip(eta1, +-scale_clip))  (klhr.py:81-85,152-174)
@@ -207,27 +210,27 @@ __device__ __forceinline__ void eval_objective(const KParams &p, const double2 *
         g[0] = -s1;
         g[1] = -(s2 + 1.0);
         g[2] = g[3] = 0.0;
-    } else if (n == 4) {
+    } else if (n != 1) {
+        constexpr bool SUB = VARIANT == VAR_SUB;          // sub_klhr_sinh.py: d == 1, e = xt[2], clip at grad_clip
         const double s_ = exp(clipc(xt[1], p.scale_clip)) + p.tol;
-        const double d_ = exp(clipc(xt[2], p.scale_clip)) + p.tol;
-        const double invd = 1.0 / d_;
-        const double a = (asx_l + xt[3]) * invd;
+        const double invd = SUB ? 1.0 : 1.0 / (exp(clipc(xt[2], p.scale_clip)) + p.tol);
+        const double a = (asx_l + (SUB ? xt[2] : xt[3])) * invd;
         const double ac = clipc(a, p.scale_clip);
         const double E = exp(ac), Ei = 1.0 / E;          // one exp serves sinh, cosh and log cosh
         const double sh = 0.5 * (E - Ei), ch = 0.5 * (E + Ei);
         const double t = xt[0] + s_ * sh;
         double logp, gdot;
         model_eval<MODEL>(p.md, [&](int i, double &xi, double &ri) { double2 v = TR[i]; ri = v.y; xi = fma(t, v.y, v.x); },
-                          p.scale_clip, NoSink(), logp, gdot);
+                          SUB ? p.grad_clip : p.scale_clip, NoSink(), logp, gdot);
         const double w = w_l;
         const double th = sh / ch;
-        const double laj = (xt[2] - xt[1]) - log_cosh_from_exp(fabs(ac), fmin(E, Ei));
+        const double laj = (SUB ? -xt[1] : xt[2] - xt[1]) - log_cosh_from_exp(fabs(ac), fmin(E, Ei));
         const double wg = w * gdot;
         double c0 = w * (laj - logp);
         double c1 = -wg;
         double c2 = -(wg * (s_ * sh)) - w;
-        double c3 = wg * (s_ * ch * a) + w * (1.0 + th * a);
-        double c4 = -(wg * (s_ * ch * invd)) - w * (th * invd);
+        double c3 = SUB ? -(wg * (s_ * ch)) - w * th : wg * (s_ * ch * a) + w * (1.0 + th * a);
+        double c4 = SUB ? 0.0 : -(wg * (s_ * ch * invd)) - w * (th * invd);
         f = grp_sum8(c0);
         g[0] = grp_sum8(c1);
         g[1] = grp_sum8(c2);
@@ -508,14 +511,15 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
                                 opt_begin(o, 2, init, 1e-5);
                             } else {
                                 // init = rng.normal(size=4) * initscale, then [0], [1] overwritten (klhr_sinh.py:191-193):
-                                // four normals are consumed, the first two discarded (no loop: keeps init[] in registers)
+                                // four normals are consumed, the first two discarded (no loop: keeps init[] in registers);
+                                // SUBKLHRSINH draws size=3 (sub_klhr_sinh.py:184)
                                 (void)rng_std_normal(rng);
                                 (void)rng_std_normal(rng);
                                 const double n2 = rng_std_normal(rng) * p.initscale;
-                                const double n3 = rng_std_normal(rng) * p.initscale;
+                                const double n3 = VARIANT == VAR_SUB ? 0.0 : rng_std_normal(rng) * p.initscale;
                                 double init[4] = {o.xk[0], s, n2, n3};
                                 for (int k = 0; k < 4; k++) dg_init[k] = init[k];
-                                opt_begin(o, 4, init, 1e-3);
+                                opt_begin(o, VARIANT == VAR_SUB ? 3 : 4, init, 1e-3);
                             }
                         } else {
                             gevals += (long long)o.nfev * 8;
@@ -539,7 +543,7 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
         // =============================================================== KL / line probes (API + tests)
         if (p.phases & (PH_KL | PH_LINE)) {
             double f, g[4];
-            eval_objective<MODEL, VARIANT>(p, TR, (p.phases & PH_KL) ? (VARIANT == VAR_GAUSS ? 2 : 4) : 1, eta, asx_l, w_l, l8, f, g);
+            eval_objective<MODEL, VARIANT>(p, TR, (p.phases & PH_KL) ? (VARIANT == VAR_GAUSS ? 2 : (VARIANT == VAR_SUB ? 3 : 4)) : 1, eta, asx_l, w_l, l8, f, g);
             if (l8 == 0) {
                 double *dd = p.d_diag + c * KLHR_NDIAG;
                 dd[0] = f; dd[1] = g[0]; dd[2] = g[1]; dd[3] = g[2]; dd[4] = g[3];
@@ -552,8 +556,8 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
             draw += 1;
             double zp;
             if constexpr (VARIANT == VAR_GAUSS) zp = gauss_zp<OVERRELAX>(rng, eta, Kc, p.scale_clip);
-            else if constexpr (OVERRELAX) zp = overrelaxed_zp(rng, eta, p.K, p.tol, p.scale_clip);
-            else zp = sa_T(rng_std_normal(rng), eta, p.tol, p.scale_clip);
+            else if constexpr (OVERRELAX) zp = overrelaxed_zp(rng, eta, p.K, p.tol, p.scale_clip, VARIANT == VAR_SUB);
+            else zp = sa_T(rng_std_normal(rng), eta, p.tol, p.scale_clip, VARIANT == VAR_SUB);
             double logp, gdot;
             const double t = (l8 == 0) ? zp : 0.0;
             model_eval<MODEL>(p.md, [&](int i, double &xi, double &ri) { double2 v = TR[i]; ri = v.y; xi = fma(t, v.y, v.x); },
@@ -567,8 +571,8 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
                 r += gauss_logq(0.0, gm, gs);
                 r -= gauss_logq(zp, gm, gs);
             } else {
-                r += sa_log_q(0.0, eta, p.tol, p.scale_clip);
-                r -= sa_log_q(zp, eta, p.tol, p.scale_clip);
+                r += sa_log_q(0.0, eta, p.tol, p.scale_clip, VARIANT == VAR_SUB);
+                r -= sa_log_q(zp, eta, p.tol, p.scale_clip, VARIANT == VAR_SUB);
             }
             const double logu = log(rng_uniform(rng));
             const double mn = (r != r) ? r : (r < 0 ? r : 0.0);      // np.minimum(0, r)
@@ -615,7 +619,7 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
                                       [&](int i, double gi) { if ((i & 7) == l8) Z[i] = gi; }, lp_, gd_);
                     KLHR_WAVE_SYNC();
                     om_update_strided(p.omd_m + c * (long long)D, p.omd_v + c * (long long)D, omN, D, l8, TR, Z, true,
-                                      VARIANT == VAR_GAUSS ? INFINITY : p.scale_clip);     // klhr.py:216 feeds the raw gradient
+                                      VARIANT == VAR_GAUSS ? INFINITY : (VARIANT == VAR_SUB ? p.grad_clip : p.scale_clip));   // klhr.py:216: raw gradient
                     KLHR_WAVE_SYNC();
                 }
                 om_update_strided(p.om_m + c * (long long)D, p.om_v + c * (long long)D, omN, D, l8, TR, Z, false, 0.0);
@@ -709,23 +713,28 @@ __global__ void klhr_logp_kernel(ModelData md, const double *thetas, long long n
 
 #ifndef KLHR_HOT_TU   // plain (non-template) kernels live in the API translation unit only
 // sinh-arcsinh primitives for n (x, eta) pairs (klhr_sinh.py:112-156,230-240)
-__global__ void klhr_prim_kernel(const double *x, const double *eta, long long n, double tol, double sc, double *out) {
+__global__ void klhr_prim_kernel(const double *x, const double *eta, long long n, double tol, double sc, double *out, int sub) {
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const double *e4 = eta + k * 4;
     const double xv = x[k];
     double m, s, d, e;
-    sa_unpack(e4, tol, sc, m, s, d, e);
+    sa_unpack(e4, tol, sc, m, s, d, e, sub != 0);
     double *o = out + k * 12;
-    o[0] = sa_T(xv, e4, tol, sc);
-    o[1] = sa_T_inv(xv, e4, tol, sc);
+    o[0] = sa_T(xv, e4, tol, sc, sub != 0);
+    o[1] = sa_T_inv(xv, e4, tol, sc, sub != 0);
     const double a_div = (asinh(xv) + e) / d;
-    o[2] = (e4[2] - e4[1]) - log(cosh(clipc(a_div, sc)));
-    o[3] = sa_log_q(xv, e4, tol, sc);
+    o[2] = (sub ? -e4[1] : e4[2] - e4[1]) - log(cosh(clipc(a_div, sc)));
+    o[3] = sa_log_q(xv, e4, tol, sc, sub != 0);
     const double invd = 1 / d, a = (asinh(xv) + e) * invd, ac = clipc(a, sc);
-    o[4] = 1.0; o[5] = s * sinh(ac); o[6] = -s * cosh(ac) * a; o[7] = s * cosh(ac) * invd;
     const double t = tanh(ac);
-    o[8] = 0.0; o[9] = -1.0; o[10] = 1 + t * a; o[11] = -t * invd;
+    if (sub) {      // sub_klhr_sinh.py:115-121,143-149
+        o[4] = 1.0; o[5] = s * sinh(ac); o[6] = s * cosh(ac); o[7] = 0.0;
+        o[8] = 0.0; o[9] = -1.0; o[10] = -t; o[11] = 0.0;
+    } else {
+        o[4] = 1.0; o[5] = s * sinh(ac); o[6] = -s * cosh(ac) * a; o[7] = s * cosh(ac) * invd;
+        o[8] = 0.0; o[9] = -1.0; o[10] = 1 + t * a; o[11] = -t * invd;
+    }
 }
 
 #endif  // KLHR_HOT_TU

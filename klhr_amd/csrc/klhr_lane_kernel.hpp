@@ -154,20 +154,21 @@ __device__ inline void lane_close_window(const KParams &p, long long c, long lon
 #define KLHR_NVG 4
 #endif
 
-template <int MODEL>
+template <int MODEL, bool SUB = false>
 __device__ __forceinline__ void lane_eval_kl(const KParams &p, const double2 *TR, const double *xt, double &f, double *g) {
     constexpr int NVG = KLHR_NVG;
+    // SUB: SUBKLHRSINH's 3-parameter proposal (sub_klhr_sinh.py): d == 1, e = xt[2], gradient clipped at grad_clip
     const double s_ = exp(clipc(xt[1], p.scale_clip)) + p.tol;
-    const double d_ = exp(clipc(xt[2], p.scale_clip)) + p.tol;
-    const double invd = 1.0 / d_;
-    const double e21 = xt[2] - xt[1];
+    const double invd = SUB ? 1.0 : 1.0 / (exp(clipc(xt[2], p.scale_clip)) + p.tol);
+    const double e21 = SUB ? -xt[1] : xt[2] - xt[1];
+    const double esh = SUB ? xt[2] : xt[3];
     double out = 0.0, g0 = 0.0, g1 = 0.0, g2 = 0.0, g3 = 0.0;
 #pragma unroll
     for (int h = 0; h < 8 / NVG; h++) {
         double sh[NVG], ch[NVG], lch[NVG], t[NVG], logp[NVG], gdot[NVG];
 #pragma unroll
         for (int n = 0; n < NVG; n++) {
-            const double a = (p.asx[h * NVG + n] + xt[3]) * invd;
+            const double a = (p.asx[h * NVG + n] + esh) * invd;
             const double ac = clipc(a, p.scale_clip);
             // one exp serves sinh and cosh: |abs error| <= 2^-53 * cosh, the same size as the rounding of the sums
             // these values enter (KL value/gradient stay within the 1e-12 parity bound, tests/test_gpu_parity.py)
@@ -177,19 +178,22 @@ __device__ __forceinline__ void lane_eval_kl(const KParams &p, const double2 *TR
             lch[n] = log_cosh_from_exp(fabs(ac), fmin(E, Ei));
             t[n] = xt[0] + s_ * sh[n];
         }
-        model_eval_nv<MODEL, NVG>(p.md, TR, t, p.scale_clip, logp, gdot);
+        model_eval_nv<MODEL, NVG>(p.md, TR, t, SUB ? p.grad_clip : p.scale_clip, logp, gdot);
 #pragma unroll
         for (int n = 0; n < NVG; n++) {
             const double w = p.wq[h * NVG + n];
-            const double a = (p.asx[h * NVG + n] + xt[3]) * invd;
+            const double a = (p.asx[h * NVG + n] + esh) * invd;
             const double th = sh[n] / ch[n];
             const double laj = e21 - lch[n];
             out += w * (laj - logp[n]);
             const double wg = w * gdot[n];
             g0 -= wg;
             g1 -= wg * (s_ * sh[n]);             g1 += w * -1.0;
-            g2 -= wg * (-s_ * ch[n] * a);        g2 += w * (1.0 + th * a);
-            g3 -= wg * (s_ * ch[n] * invd);      g3 += w * (-th * invd);
+            if (SUB) { g2 -= wg * (s_ * ch[n]);      g2 += w * (-th); }
+            else {
+                g2 -= wg * (-s_ * ch[n] * a);    g2 += w * (1.0 + th * a);
+                g3 -= wg * (s_ * ch[n] * invd);  g3 += w * (-th * invd);
+            }
         }
     }
     f = out; g[0] = g0; g[1] = g1; g[2] = g2; g[3] = g3;
@@ -303,11 +307,11 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
                 double x0v[4] = {0, 0, 0, 0};
                 if (active) {
                     x0v[0] = rng_std_normal(rng) * p.initscale;
-                    if (VARIANT == VAR_SINH) {               // klhr.py's fit draws no further normals (klhr.py:134-139)
+                    if (VARIANT != VAR_GAUSS) {              // klhr.py's fit draws no further normals (klhr.py:134-139)
                         (void)rng_std_normal(rng);
                         (void)rng_std_normal(rng);
                         fit_n2 = rng_std_normal(rng) * p.initscale;
-                        fit_n3 = rng_std_normal(rng) * p.initscale;
+                        if (VARIANT == VAR_SINH) fit_n3 = rng_std_normal(rng) * p.initscale;     // size = 3 for SUBKLHRSINH
                     }
                 }
                 if (diag && active) dd[KLHR_D_X0] = x0v[0];
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
                 if (ev1) lane_eval_line<MODEL>(p, TR, o.xt[0], f, g);
                 if (ev4) {
                     if constexpr (VARIANT == VAR_GAUSS) lane_eval_kl_gauss<MODEL>(p, TR, o.xt, f, g);
-                    else lane_eval_kl<MODEL>(p, TR, o.xt, f, g);
+                    else lane_eval_kl<MODEL, VARIANT == VAR_SUB>(p, TR, o.xt, f, g);
                 }
                 if (!done) {
                     if (hit) { f = o.lf; g[0] = o.lg[0]; g[1] = o.lg[1]; g[2] = o.lg[2]; g[3] = o.lg[3]; }
@@ -341,7 +345,7 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
                             double init[4] = {o.xk[0], s, fit_n2, fit_n3};
                             if (diag) { dd[KLHR_D_INIT0] = init[0]; dd[KLHR_D_INIT1] = init[1]; dd[KLHR_D_INIT2] = init[2]; dd[KLHR_D_INIT3] = init[3]; }
                             if (VARIANT == VAR_GAUSS) opt_begin(o, 2, init, 1e-5);      // klhr.py:136-139: default gtol
-                            else opt_begin(o, 4, init, 1e-3);
+                            else opt_begin(o, VARIANT == VAR_SUB ? 3 : 4, init, 1e-3);
                         } else {
                             gevals += (long long)o.nfev * 8;
                             for (int k = 0; k < 4; k++) eta[k] = o.xk[k];
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
             double f, g[4];
             if (p.phases & PH_KL) {
                 if constexpr (VARIANT == VAR_GAUSS) lane_eval_kl_gauss<MODEL>(p, TR, eta, f, g);
-                else lane_eval_kl<MODEL>(p, TR, eta, f, g);
+                else lane_eval_kl<MODEL, VARIANT == VAR_SUB>(p, TR, eta, f, g);
             } else lane_eval_line<MODEL>(p, TR, eta[0], f, g);
             double *dp = p.d_diag + c * KLHR_NDIAG;
             dp[0] = f; dp[1] = g[0]; dp[2] = g[1]; dp[3] = g[2]; dp[4] = g[3];
@@ -378,8 +382,8 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
             draw += 1;
             double zp;
             if constexpr (VARIANT == VAR_GAUSS) zp = gauss_zp<OVERRELAX>(rng, eta, Kc, p.scale_clip);
-            else if constexpr (OVERRELAX) zp = overrelaxed_zp(rng, eta, p.K, p.tol, p.scale_clip);
-            else zp = sa_T(rng_std_normal(rng), eta, p.tol, p.scale_clip);
+            else if constexpr (OVERRELAX) zp = overrelaxed_zp(rng, eta, p.K, p.tol, p.scale_clip, VARIANT == VAR_SUB);
+            else zp = sa_T(rng_std_normal(rng), eta, p.tol, p.scale_clip, VARIANT == VAR_SUB);
             double t2[2] = {zp, 0.0}, lp2[2], gd2[2];
             model_eval_nv<MODEL, 2>(p.md, TR, t2, INFINITY, lp2, gd2);
             double r = lp2[0];
@@ -389,8 +393,8 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
                 r += gauss_logq(0.0, gm, gs);
                 r -= gauss_logq(zp, gm, gs);
             } else {
-                r += sa_log_q(0.0, eta, p.tol, p.scale_clip);
-                r -= sa_log_q(zp, eta, p.tol, p.scale_clip);
+                r += sa_log_q(0.0, eta, p.tol, p.scale_clip, VARIANT == VAR_SUB);
+                r -= sa_log_q(zp, eta, p.tol, p.scale_clip, VARIANT == VAR_SUB);
             }
             const double logu = log(rng_uniform(rng));
             const double mn = (r != r) ? r : (r < 0 ? r : 0.0);
@@ -433,7 +437,7 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
                     model_eval<MODEL>(p.md, [&](int i, double &xi, double &ri) { xi = TR[i].x; ri = 0.0; }, INFINITY,
                                       [&](int i, double gi) { Z[i] = gi; }, lp_, gd_);
                     lane_om_update(p.omd_m + c * (long long)D, p.omd_v + c * (long long)D, omN, D, TR, Z, true,
-                                   VARIANT == VAR_GAUSS ? INFINITY : p.scale_clip);
+                                   VARIANT == VAR_GAUSS ? INFINITY : (VARIANT == VAR_SUB ? p.grad_clip : p.scale_clip));
                 }
                 lane_om_update(p.om_m + c * (long long)D, p.om_v + c * (long long)D, omN, D, TR, Z, false, 0.0);
                 const double *mean = p.mean + c * (long long)D;

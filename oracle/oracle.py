@@ -132,6 +132,8 @@ class Chain:
         self.variant = variant
         if variant == "gauss":
             L.klhr_oracle_set_variant(self._h, 1)
+        elif variant == "sub":
+            L.klhr_oracle_set_variant(self._h, 2)
         self.init_tries = None
         if seed is not None:
             self.init_tries = L.klhr_oracle_seed(self._h, int(seed), None)

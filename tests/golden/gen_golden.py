@@ -34,6 +34,7 @@ sys.path.insert(0, ROOT)
 
 import klhr_sinh as ref_klhr_sinh          # noqa: E402  (reference)
 import klhr as ref_klhr                    # noqa: E402  (reference, Gaussian-proposal sibling)
+import sub_klhr_sinh as ref_sub            # noqa: E402  (reference, 3-parameter sibling)
 import mh as ref_mh                        # noqa: E402
 import onlinemoments as ref_om             # noqa: E402
 import onlinepca as ref_pca                # noqa: E402
@@ -250,10 +251,12 @@ def g7_online():
 SNAP_DRAWS = {1, 2, 3, 5, 6, 7, 10, 25, 49, 50, 51, 52, 60, 99, 100, 101, 120, 150}
 
 
-def trace_chain(name, seed, M, warmup, **flags):
-    """Run the reference KLHRSINH for M draws, recording per-iteration inputs/outputs."""
+def trace_chain(name, seed, M, warmup, mod=None, cls="KLHRSINH", **flags):
+    """Run the reference KLHRSINH (or SUBKLHRSINH: mod=ref_sub, cls="SUBKLHRSINH") for M draws, recording per-iteration
+    inputs/outputs."""
+    ref_mod = mod or ref_klhr_sinh
     model = make_model(name)
-    algo = ref_klhr_sinh.KLHRSINH(model, seed=seed, warmup=warmup, overrelaxed=False, **flags)
+    algo = getattr(ref_mod, cls)(model, seed=seed, warmup=warmup, overrelaxed=False, **flags)
     D = algo.D
     rec = {k: [] for k in
            ["state_before", "theta_before", "rho", "x0", "mode", "hinv1", "nfev1", "nit1", "status1", "init", "eta",
@@ -263,7 +266,7 @@ def trace_chain(name, seed, M, warmup, **flags):
     theta0 = algo.theta.copy()
     state_init = st4(algo.rng)
     results = []
-    real_minimize = ref_klhr_sinh.minimize
+    real_minimize = ref_mod.minimize
 
     def rec_minimize(fun, x0, *a, **k):
         x0c = np.array(x0, dtype=np.float64).reshape(-1).copy()
@@ -271,7 +274,7 @@ def trace_chain(name, seed, M, warmup, **flags):
         results.append((o, x0c))
         return o
 
-    ref_klhr_sinh.minimize = rec_minimize
+    ref_mod.minimize = rec_minimize
     try:
         for m in range(1, M + 1):
             rec["state_before"].append(st4(algo.rng))
@@ -349,7 +352,7 @@ def trace_chain(name, seed, M, warmup, **flags):
                                 omd_v=algo._onlinemoments_density.v.copy(),
                                 pca_n=algo._onlinepca.n, pca_v=algo._onlinepca.v.copy())
     finally:
-        ref_klhr_sinh.minimize = real_minimize
+        ref_mod.minimize = real_minimize
     out = {"theta0": theta0, "state_init": state_init, "seed": np.array([seed]), "M": np.array([M]),
            "warmup": np.array([warmup]), "D": np.array([D]),
            "flags": np.array([int(flags.get("scale_dir_cov", False)), int(flags.get("eigen_method_one", False))])}
@@ -454,6 +457,16 @@ def trace_chain_klhr(name, seed, M, warmup, **flags):
     return out
 
 
+def g12_sub():
+    for name, seed, M, warmup in [("funnel10", 0, 400, 100), ("normal2", 0, 200, 100), ("illnormal100", 0, 130, 100)]:
+        fn = os.path.join(HERE, f"g12_sub_{name}_s{seed}_w{warmup}.npz")
+        print("tracing", fn, flush=True)
+        np.savez(fn, **trace_chain(name, seed, M, warmup, mod=ref_sub, cls="SUBKLHRSINH"))
+    algo = ref_sub.SUBKLHRSINH(make_model("funnel10"), seed=0, warmup=100, overrelaxed=False)
+    np.savez(os.path.join(HERE, "g12_sub_public_api.npz"), s0_thetas=np.array([algo.draw() for _ in range(80)]),
+             s0_grad_evals=np.array([algo.grad_evals]))
+
+
 def g11_klhr():
     for name, seed, M, warmup, flags in [("funnel10", 0, 400, 100, {}), ("funnel10", 1, 400, 100, {"eigen_method_one": False}),
                                          ("normal2", 0, 300, 100, {}), ("illnormal100", 0, 130, 100, {})]:
@@ -535,9 +548,9 @@ def g10_overrelaxed():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g7", "g8", "g8p", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g7", "g8", "g8p", "g9", "g10", "g11", "g12"]
     fns = {"g1": g1_quadrature, "g2": g2_rng, "g3": g3_primitives, "g4": g4_kl, "g7": g7_online,
-           "g8": g8_chains, "g8p": g8_untouched, "g9": g9_mh, "g10": g10_overrelaxed, "g11": g11_klhr}
+           "g8": g8_chains, "g8p": g8_untouched, "g9": g9_mh, "g10": g10_overrelaxed, "g11": g11_klhr, "g12": g12_sub}
     for w in which:
         print("==", w, flush=True)
         fns[w]()

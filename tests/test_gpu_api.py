@@ -228,3 +228,19 @@ def test_klhr_class_is_the_reference_chain():
     many = KLHR(funnel_model(), seed=3, warmup=100, chains=300, overrelaxed=True)
     many.draws(150)
     assert many.K.shape == (300,) and many.K.min() >= 1 and many.K.max() <= 50
+
+
+def test_subklhrsinh_class():
+    from klhr_amd import SUBKLHRSINH
+    g = golden("g12_sub_public_api.npz")
+    algo = SUBKLHRSINH(funnel_model(), seed=0, warmup=100, overrelaxed=False)
+    th = np.array([algo.draw() for _ in range(50)])
+    assert np.abs(th - g["s0_thetas"][:50]).max() < 1e-9
+    rho = algo._random_direction()
+    eta = algo.fit(rho)
+    assert eta.shape == (3,)
+    v, grad = algo.KL(eta, rho)
+    assert grad.shape == (3,) and np.max(np.abs(grad)) < 1e-3
+    assert algo._grad_T(0.2, eta).shape == (3,)
+    many = SUBKLHRSINH(funnel_model(), seed=1, warmup=100, chains=128)      # reference default: overrelaxed=True
+    assert np.isfinite(many.draws(120)).all()

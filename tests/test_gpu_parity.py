@@ -409,3 +409,63 @@ def test_klhr_free_running_vs_reference():
     err = np.abs(dr - g["theta_after"][:120]).max(axis=1)
     assert err[:50].max() < 1e-9
     assert int(s.get("kstate")[0, 2]) == g["K"][119]
+
+
+G12 = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "g12_sub_*_w*.npz")))
+
+
+@pytest.mark.parametrize("fn", G12)
+def test_sub_variant_vs_oracle(oracle, fn):
+    """SUBKLHRSINH (3-parameter proposal).  Per-record teacher forcing of fit and MH step against the oracle."""
+    name = fn[len("g12_sub_"):-4].split("_")[0]
+    g = golden(fn)
+    stem, data = model_spec(name)
+    M, warmup = min(int(g["M"][0]), 300), int(g["warmup"][0])
+    # records before the first window closure share the initial adaptation state (mean 0, cov 1, no eigenvectors)
+    M = min(M, 49)
+    s = make_sampler(stem, data, M, warmup=warmup, variant=2)
+    s.set("theta", g["theta_before"][:M]); s.set("rng", g["state_before"][:M])
+    cnt = np.zeros((M, 4), dtype=np.int64); cnt[:, 0] = np.arange(M)
+    s.set("counters", cnt)
+    rho = s.random_direction()
+    assert np.allclose(rho, g["rho"][:M], rtol=1e-13, atol=1e-15)    # pre-closure direction: pure RNG + normalisation
+    eta = s.fit(g["rho"][:M])
+    assert np.array_equal(s.get("rng"), g["state_mh"][:M])   # 1 + 3 normals consumed
+    d = s.get("diag")
+    from klhr_amd._lib import DIAG_COLS as DC
+    col = {k: i for i, k in enumerate(DC)}
+    o_eta, o_n1, o_n2 = [], [], []
+    for m in range(M):
+        o = oracle.Chain(stem, data, seed=0, warmup=warmup, variant="sub")
+        o.set("theta", g["theta_before"][m]); o.set("rng", g["state_before"][m])
+        o.random_direction()
+        o_eta.append(o.fit(g["rho"][m])); dd = o.get("diag"); o_n1.append(dd["nfev1"]); o_n2.append(dd["nfev2"])
+    o_eta = np.array(o_eta)
+    same = (d[:, col["nfev1"]] == np.array(o_n1)) & (d[:, col["nfev2"]] == np.array(o_n2))
+    assert same.mean() >= 0.95, same.mean()
+    err = np.abs(eta[:, :3] - o_eta[:, :3]) / (1 + np.abs(o_eta[:, :3]))
+    assert np.all(err[same] < 2e-6) and np.all(eta[:, 3] == 0)
+    assert np.array_equal(d[:, col["init2"]], g["init"][:M, 2]) and np.all(d[:, col["init3"]] == 0)
+    s.set("counters", cnt)
+    e4 = np.zeros((M, 4)); e4[:, :3] = g["eta"][:M]
+    s.metropolis(e4, g["rho"][:M])
+    d = s.get("diag")
+    assert np.array_equal(s.get("rng"), g["state_after"][:M])
+    assert np.all(np.abs(d[:, col["zp"]] - g["zp"][:M]) <= 1e-11 * (1 + np.abs(g["zp"][:M])))
+    assert np.all(np.abs(d[:, col["r"]] - g["r"][:M]) <= 1e-9 * (1 + np.abs(g["r"][:M])))
+    clear = np.abs(g["logu"][:M] - np.minimum(0.0, g["r"][:M])) > 1e-8
+    assert np.array_equal(d[clear, col["accept"]].astype(bool), g["accept"][:M][clear])
+
+
+def test_sub_free_running_vs_reference():
+    g = golden("g12_sub_funnel10_s0_w100.npz")
+    stem, data = model_spec("funnel10")
+    s = make_sampler(stem, data, 1, warmup=100, variant=2)
+    s.seed(np.array([0], dtype=np.uint64))
+    s.step(120, record_draws=True)
+    dr = s.draws(0, 120)[:, 0]
+    err = np.abs(dr - g["theta_after"][:120]).max(axis=1)
+    assert err[:50].max() < 1e-9
+    bad = np.flatnonzero(err > 1e-6)
+    first = int(bad[0]) if bad.size else 120
+    assert np.array_equal(np.any(dr[1:first] != dr[:first - 1], axis=1), g["accept"][1:first])
