@@ -18,6 +18,7 @@
 //   gdot            = sum_i clip(g_i) * rho_i   — the only thing the hot loop needs from the gradient
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 namespace klhr {
 
@@ -45,40 +46,53 @@ __device__ __forceinline__ void model_eval(const ModelData &md, XR xr, double cl
         const double Da = (double)md.n;
         const double ev = exp(-v);
         double ss = 0.0, gd = 0.0;
-        for (int i = 1; i < D; i++) {
-            double xi, ri;
-            xr(i, xi, ri);
-            ss += xi * xi;
-            double gi = -ev * xi;
-            sink(i, gi);
-            gd += clipc(gi, cl) * ri;
+        if (std::is_same<SINK, NoSink>::value && ev > 0.0 && ev < INFINITY) {
+            // hot path (no gradient sink): clip with v_max/v_min; with exp(-v) finite and positive g_i is NaN exactly
+            // when xi is, i.e. exactly when ss ends up NaN, so np.clip's NaN propagation is restored after the loop
+            for (int i = 1; i < D; i++) {
+                double xi, ri;
+                xr(i, xi, ri);
+                ss += xi * xi;
+                gd += fmin(fmax(-ev * xi, -cl), cl) * ri;
+            }
+            if (ss != ss) gd = NAN;
+        } else {
+            for (int i = 1; i < D; i++) {
+                double xi, ri;
+                xr(i, xi, ri);
+                ss += xi * xi;
+                double gi = -ev * xi;
+                sink(i, gi);
+                gd += clipc(gi, cl) * ri;
+            }
         }
         double g0 = -v / 9.0 - 0.5 * Da + 0.5 * ev * ss;
         sink(0, g0);
         gdot = clipc(g0, cl) * r0 + gd;
         logp = -v * v / 18.0 - 0.5 * Da * v - 0.5 * ev * ss;
-    } else if constexpr (MODEL == MODEL_ILL_NORMAL) {
+    } else if constexpr (MODEL == MODEL_ILL_NORMAL || MODEL == MODEL_NORMAL) {
         double acc = 0.0, gd = 0.0;
-        for (int i = 0; i < D; i++) {
-            double xi, ri;
-            xr(i, xi, ri);
-            double is = md.aux[i];
-            double z = xi * is;
-            acc += z * z;
-            double gi = -z * is;
-            sink(i, gi);
-            gd += clipc(gi, cl) * ri;
-        }
-        gdot = gd;
-        logp = -0.5 * acc;
-    } else if constexpr (MODEL == MODEL_NORMAL) {
-        double acc = 0.0, gd = 0.0;
-        for (int i = 0; i < D; i++) {
-            double xi, ri;
-            xr(i, xi, ri);
-            acc += xi * xi;
-            sink(i, -xi);
-            gd += clipc(-xi, cl) * ri;
+        if (std::is_same<SINK, NoSink>::value) {
+            // hot path: g_i = -xi / s_i^2 is NaN exactly when acc ends up NaN (s_i finite, non-zero)
+            for (int i = 0; i < D; i++) {
+                double xi, ri;
+                xr(i, xi, ri);
+                double gi;
+                if constexpr (MODEL == MODEL_ILL_NORMAL) { double is = md.aux[i]; double z = xi * is; acc += z * z; gi = -z * is; }
+                else { acc += xi * xi; gi = -xi; }
+                gd += fmin(fmax(gi, -cl), cl) * ri;
+            }
+            if (acc != acc) gd = NAN;
+        } else {
+            for (int i = 0; i < D; i++) {
+                double xi, ri;
+                xr(i, xi, ri);
+                double gi;
+                if constexpr (MODEL == MODEL_ILL_NORMAL) { double is = md.aux[i]; double z = xi * is; acc += z * z; gi = -z * is; }
+                else { acc += xi * xi; gi = -xi; }
+                sink(i, gi);
+                gd += clipc(gi, cl) * ri;
+            }
         }
         gdot = gd;
         logp = -0.5 * acc;
