@@ -45,8 +45,11 @@ enum klhr_status {
  *   FUNNEL        [D_alpha]                       stan/funnel.stan      (dim = D_alpha + 1)
  *   ILL_NORMAL    [D]                             stan/ill-normal.stan
  *   GLMM_POISSON  [n, year_1..year_n, C_1..C_n]   stan/glmm-poisson.stan (dim = n + 5)
- *   NORMAL        [D]                             stan/normal.stan                              */
-enum klhr_model { KLHR_MODEL_FUNNEL = 0, KLHR_MODEL_ILL_NORMAL = 1, KLHR_MODEL_GLMM_POISSON = 2, KLHR_MODEL_NORMAL = 3 };
+ *   NORMAL        [D]                             stan/normal.stan
+ *   AR1           [N]                             stan/ar1.stan          (dim = N)
+ *   EARNINGS      [N, earn_1..N, height_1..N]     stan/earnings.stan     (dim = 4: beta_1, beta_2, log sigma, log s) */
+enum klhr_model { KLHR_MODEL_FUNNEL = 0, KLHR_MODEL_ILL_NORMAL = 1, KLHR_MODEL_GLMM_POISSON = 2, KLHR_MODEL_NORMAL = 3,
+                  KLHR_MODEL_AR1 = 4, KLHR_MODEL_EARNINGS = 5 };
 
 /* Mirrors KLHRSINH.__init__ keyword arguments (klhr_sinh.py:15-32) plus `chains` and `device`. */
 typedef struct klhr_config {

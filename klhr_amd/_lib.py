@@ -13,7 +13,7 @@ DIAG_COLS = ["x0", "mode", "hinv1", "nfev1", "nit1", "status1", "init0", "init1"
              "status2", "fun2", "zp", "r", "logu", "accept", "fallbacks", "passes"]
 FIELDS = dict(theta=0, rng=1, mean=2, cov=3, eigvecs=4, eigvals=5, om_m=6, om_v=7, omd_m=8, omd_v=9, pca_v=10, counters=11,
               acc=12, grad_evals=13, rho=14, eta=15, diag=16, status=17, kstate=18)
-MODEL_IDS = {"funnel": 0, "ill-normal": 1, "glmm-poisson": 2, "normal": 3}
+MODEL_IDS = {"funnel": 0, "ill-normal": 1, "glmm-poisson": 2, "normal": 3, "ar1": 4, "earnings": 5}
 
 
 class KlhrError(RuntimeError):

@@ -14,7 +14,7 @@ import numpy as np
 from . import _lib
 
 _STEMS = {"funnel": "funnel", "funnel-100": "funnel", "ill-normal": "ill-normal", "glmm-poisson": "glmm-poisson",
-          "normal": "normal", "normal-100": "normal"}
+          "normal": "normal", "normal-100": "normal", "ar1": "ar1", "earnings": "earnings"}
 
 
 def pack_model_data(stem, data):
@@ -27,6 +27,13 @@ def pack_model_data(stem, data):
         if year.size != int(data["n"]) or counts.size != int(data["n"]):
             raise ValueError("glmm-poisson data: len(year), len(C) must equal n")
         return np.concatenate([[float(data["n"])], year, counts])
+    if stem == "ar1":
+        return np.array([float(data["N"])])
+    if stem == "earnings":
+        earn, height = np.asarray(data["earn"], dtype=np.float64), np.asarray(data["height"], dtype=np.float64)
+        if earn.size != int(data["N"]) or height.size != int(data["N"]):
+            raise ValueError("earnings data: len(earn), len(height) must equal N")
+        return np.concatenate([[float(data["N"])], earn, height])
     raise KeyError(stem)
 
 
@@ -46,7 +53,8 @@ class BSModel:
         self.model_data = pack_model_data(self.stem, data)
         self.device = device
         self._D = {"funnel": lambda: int(data["D"]) + 1, "ill-normal": lambda: int(data["D"]),
-                   "normal": lambda: int(data["D"]), "glmm-poisson": lambda: int(data["n"]) + 5}[self.stem]()
+                   "normal": lambda: int(data["D"]), "glmm-poisson": lambda: int(data["n"]) + 5,
+                   "ar1": lambda: int(data["N"]), "earnings": lambda: 4}[self.stem]()
         self._probe = None          # a 1-chain handle used for host-side evaluations
 
     # -- device plumbing
@@ -100,6 +108,8 @@ class BSModel:
             sigma = np.exp(theta[4])
             theta[4] = sigma
             theta[5:] = sigma * theta[5:]      # vector<multiplier=sigma> eps
+        if self.stem == "earnings":
+            theta[2:4] = np.exp(theta[2:4])    # real<lower=0> sigma, s
         return theta
 
     def unconstrain(self, theta):
@@ -108,6 +118,8 @@ class BSModel:
             sigma = theta[4]
             theta[5:] = theta[5:] / sigma
             theta[4] = np.log(sigma)
+        if self.stem == "earnings":
+            theta[2:4] = np.log(theta[2:4])
         return theta
 
     def parameter_names(self):
@@ -115,4 +127,6 @@ class BSModel:
             return ["double_log_sigma"] + [f"alpha.{i + 1}" for i in range(self._D - 1)]
         if self.stem == "glmm-poisson":
             return ["alpha", "beta.1", "beta.2", "beta.3", "sigma"] + [f"eps.{i + 1}" for i in range(self._D - 5)]
+        if self.stem == "earnings":
+            return ["beta.1", "beta.2", "sigma", "s"]
         return [f"y.{i + 1}" for i in range(self._D)]

@@ -9,6 +9,9 @@
 //                 lp = -alpha^2/50 - sum(beta^2)/50 - l^2/2 - sum(eps~^2)/2 + sum(C_i*eta_i - exp(eta_i)),
 //                 eta_i = alpha + x_i.beta + exp(l)*eps~_i
 //   NORMAL        stan/normal.stan:4-8        lp = -sum(y^2)/2
+//   AR1           stan/ar1.stan:1-14          y_1 ~ N(0,1), y_i ~ N(0.9 y_{i-1}, sqrt(1 - 0.81))
+//   EARNINGS      stan/earnings.stan:1-17     theta = (beta_1, beta_2, log sigma, log s); Gaussian likelihood through
+//                                             centred sufficient statistics aux = [N, mean(earn), mean(height), See, Seh, Shh]
 //
 // One generic evaluator per model:  model_eval<MODEL>(md, xr, cl, sink, logp, gdot)
 //   xr(i, xi, ri)   supplies coordinate i of the evaluation point and of the direction rho
@@ -22,7 +25,7 @@
 
 namespace klhr {
 
-enum { MODEL_FUNNEL = 0, MODEL_ILL_NORMAL = 1, MODEL_GLMM_POISSON = 2, MODEL_NORMAL = 3 };
+enum { MODEL_FUNNEL = 0, MODEL_ILL_NORMAL = 1, MODEL_GLMM_POISSON = 2, MODEL_NORMAL = 3, MODEL_AR1 = 4, MODEL_EARNINGS = 5 };
 
 struct ModelData {
     const double *aux;   // ILL_NORMAL: [1/s_i (D)] ; GLMM: [x1(n), x2(n), x3(n), C(n)]
@@ -96,6 +99,52 @@ __device__ __forceinline__ void model_eval(const ModelData &md, XR xr, double cl
         }
         gdot = gd;
         logp = -0.5 * acc;
+    } else if constexpr (MODEL == MODEL_AR1) {
+        // one pass with a one-step delay: g_{i-1} = -(z_{i-1} [/beta]) + alpha z_i / beta is complete once z_i is known
+        const double a = 0.9, b = sqrt(1 - a * a);
+        double xp, rp;
+        xr(0, xp, rp);
+        double lp = -0.5 * xp * xp;
+        double gprev = -xp;              // partial gradient of coordinate i-1
+        double gd = 0.0;
+        for (int i = 1; i < D; i++) {
+            double xi, ri;
+            xr(i, xi, ri);
+            double z = (xi - a * xp) / b;
+            lp -= 0.5 * z * z;
+            double gfull = gprev + a * z / b;
+            sink(i - 1, gfull);
+            gd += clipc(gfull, cl) * rp;
+            gprev = -z / b;
+            xp = xi; rp = ri;
+        }
+        sink(D - 1, gprev);
+        gd += clipc(gprev, cl) * rp;
+        gdot = gd;
+        logp = lp;
+    } else if constexpr (MODEL == MODEL_EARNINGS) {
+        const double N = md.aux[0], eb = md.aux[1], hb = md.aux[2], See = md.aux[3], Seh = md.aux[4], Shh = md.aux[5];
+        double b1, b2, lsig, ls, r1, r2, r3, r4;
+        xr(0, b1, r1); xr(1, b2, r2); xr(2, lsig, r3); xr(3, ls, r4);
+        const double sigma = exp(lsig), sc = exp(ls);
+        const double delta = eb - b1 - b2 * hb;
+        const double SS = See - 2 * b2 * Seh + b2 * b2 * Shh + N * delta * delta;
+        const double q1 = b1 * b1 / (5 * sc * sc), q2 = b2 * b2 / (5 * sc * sc);
+        double lp = -0.01 * sc + ls;
+        lp += -3 * log1p(q1) - ls;
+        lp += -3 * log1p(q2) - ls;
+        lp += -0.1 * sigma + lsig;
+        lp += -N * lsig - SS / (2 * sigma * sigma);
+        const double i2 = 1 / (sigma * sigma);
+        const double g0 = -6 * b1 / (5 * sc * sc + b1 * b1) + N * delta * i2;
+        const double g1 = -6 * b2 / (5 * sc * sc + b2 * b2) + (Seh - b2 * Shh + N * delta * hb) * i2;
+        const double g2 = -0.1 * sigma + 1 - N + SS * i2;
+        const double g3 = -0.01 * sc + 1 + (6 * q1 / (1 + q1) - 1) + (6 * q2 / (1 + q2) - 1);
+        sink(0, g0); sink(1, g1); sink(2, g2); sink(3, g3);
+        double gd = clipc(g0, cl) * r1;
+        gd += clipc(g1, cl) * r2; gd += clipc(g2, cl) * r3; gd += clipc(g3, cl) * r4;
+        gdot = gd;
+        logp = lp;
     } else {   // MODEL_GLMM_POISSON
         const int n = md.n;
         const double *x1 = md.aux, *x2 = md.aux + n, *x3 = md.aux + 2 * n, *Cn = md.aux + 3 * n;
@@ -140,7 +189,11 @@ template <int MODEL, class SUM8>
 __device__ __forceinline__ void model_eval_split(const ModelData &md, const double2 *TR, double t, double cl, int l8, SUM8 sum8,
                                                  double &logp, double &gdot) {
     const int D = md.D;
-    if constexpr (MODEL == MODEL_FUNNEL) {
+    if constexpr (MODEL == MODEL_AR1 || MODEL == MODEL_EARNINGS) {
+        // chained (AR1) / 4-dimensional (earnings) targets: every lane of the octet evaluates the whole point
+        model_eval<MODEL>(md, [&](int i, double &xi, double &ri) { double2 v = TR[i]; ri = v.y; xi = fma(t, v.y, v.x); }, cl,
+                          NoSink(), logp, gdot);
+    } else if constexpr (MODEL == MODEL_FUNNEL) {
         const double2 e0 = TR[0];
         const double v = fma(t, e0.y, e0.x);
         const double Da = (double)md.n;
@@ -221,7 +274,14 @@ template <int MODEL, int NV>
 __device__ __forceinline__ void model_eval_nv(const ModelData &md, const double2 *TR, const double (&t)[NV], double cl,
                                               double (&logp)[NV], double (&gdot)[NV]) {
     const int D = md.D;
-    if constexpr (MODEL == MODEL_FUNNEL) {
+    if constexpr (MODEL == MODEL_AR1 || MODEL == MODEL_EARNINGS) {
+#pragma unroll
+        for (int n = 0; n < NV; n++) {
+            const double tn = t[n];
+            model_eval<MODEL>(md, [&](int i, double &xi, double &ri) { double2 v = TR[i]; ri = v.y; xi = fma(tn, v.y, v.x); }, cl,
+                              NoSink(), logp[n], gdot[n]);
+        }
+    } else if constexpr (MODEL == MODEL_FUNNEL) {
         const double2 e0 = TR[0];
         const double Da = (double)md.n;
         double v[NV], ev[NV], ss[NV], gd[NV];

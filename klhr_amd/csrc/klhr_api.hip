@@ -207,6 +207,18 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
             aux[i] = y; aux[n + i] = y * y; aux[2 * n + i] = y * y * y; aux[3 * n + i] = model_data[1 + n + i];
         }
         break;
+    case KLHR_MODEL_AR1: D = (int)model_data[0]; break;
+    case KLHR_MODEL_EARNINGS: {
+        n = (int)model_data[0];
+        if (n < 2 || n_model_data < (size_t)(1 + 2 * n)) return fail("klhr_create: earnings data too short");
+        D = 4;
+        double eb = 0, hb = 0;
+        for (int i = 0; i < n; i++) { eb += model_data[1 + i]; hb += model_data[1 + n + i]; }
+        eb /= n; hb /= n;
+        double see = 0, seh = 0, shh = 0;
+        for (int i = 0; i < n; i++) { double ec = model_data[1 + i] - eb, hc = model_data[1 + n + i] - hb; see += ec * ec; seh += ec * hc; shh += hc * hc; }
+        aux = {(double)n, eb, hb, see, seh, shh};
+        break; }
     default: return fail("klhr_create: unknown model_id");
     }
     if (D < 1) return fail("klhr_create: model dimension < 1");
@@ -376,6 +388,8 @@ static int launch_by_model(klhr_sampler *s, F f) {
     case KLHR_MODEL_FUNNEL: f(std::integral_constant<int, MODEL_FUNNEL>()); break;
     case KLHR_MODEL_ILL_NORMAL: f(std::integral_constant<int, MODEL_ILL_NORMAL>()); break;
     case KLHR_MODEL_GLMM_POISSON: f(std::integral_constant<int, MODEL_GLMM_POISSON>()); break;
+    case KLHR_MODEL_AR1: f(std::integral_constant<int, MODEL_AR1>()); break;
+    case KLHR_MODEL_EARNINGS: f(std::integral_constant<int, MODEL_EARNINGS>()); break;
     default: f(std::integral_constant<int, MODEL_NORMAL>()); break;
     }
     HIPCHECK(s, hipGetLastError());

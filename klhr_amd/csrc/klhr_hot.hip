@@ -24,6 +24,8 @@ void KLHR_CAT(launch_hot_v, KLHR_VARIANT, _o, KLHR_OVERRELAX)(const KParams &kp,
         case KLHR_MODEL_FUNNEL: hipLaunchKernelGGL((klhr_lane_kernel<MODEL_FUNNEL, O, V>), grid, block, lds, stream, kp); break;
         case KLHR_MODEL_ILL_NORMAL: hipLaunchKernelGGL((klhr_lane_kernel<MODEL_ILL_NORMAL, O, V>), grid, block, lds, stream, kp); break;
         case KLHR_MODEL_GLMM_POISSON: hipLaunchKernelGGL((klhr_lane_kernel<MODEL_GLMM_POISSON, O, V>), grid, block, lds, stream, kp); break;
+        case KLHR_MODEL_AR1: hipLaunchKernelGGL((klhr_lane_kernel<MODEL_AR1, O, V>), grid, block, lds, stream, kp); break;
+        case KLHR_MODEL_EARNINGS: hipLaunchKernelGGL((klhr_lane_kernel<MODEL_EARNINGS, O, V>), grid, block, lds, stream, kp); break;
         default: hipLaunchKernelGGL((klhr_lane_kernel<MODEL_NORMAL, O, V>), grid, block, lds, stream, kp); break;
         }
     } else {
@@ -33,6 +35,8 @@ void KLHR_CAT(launch_hot_v, KLHR_VARIANT, _o, KLHR_OVERRELAX)(const KParams &kp,
         case KLHR_MODEL_FUNNEL: hipLaunchKernelGGL((klhr_iter_kernel<MODEL_FUNNEL, O, V>), grid, block, lds, stream, kp); break;
         case KLHR_MODEL_ILL_NORMAL: hipLaunchKernelGGL((klhr_iter_kernel<MODEL_ILL_NORMAL, O, V>), grid, block, lds, stream, kp); break;
         case KLHR_MODEL_GLMM_POISSON: hipLaunchKernelGGL((klhr_iter_kernel<MODEL_GLMM_POISSON, O, V>), grid, block, lds, stream, kp); break;
+        case KLHR_MODEL_AR1: hipLaunchKernelGGL((klhr_iter_kernel<MODEL_AR1, O, V>), grid, block, lds, stream, kp); break;
+        case KLHR_MODEL_EARNINGS: hipLaunchKernelGGL((klhr_iter_kernel<MODEL_EARNINGS, O, V>), grid, block, lds, stream, kp); break;
         default: hipLaunchKernelGGL((klhr_iter_kernel<MODEL_NORMAL, O, V>), grid, block, lds, stream, kp); break;
         }
     }

@@ -70,12 +70,17 @@ __device__ __forceinline__ double dpp_move(double v, const int ctrl_sel) {
     else { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xF, 0xF, false); }
     return __hiloint2double(hi, lo);
 }
+// contract(off) is load-bearing: if the caller's product w*x were fused into the first add, lane i would compute
+// fma(w_i, x_i, round(w_j x_j)) and lane j fma(w_j, x_j, round(w_i x_i)) — sums that differ in the last bit, after which
+// the lanes of an octet can take different branches of the optimiser and lose lockstep.
+#pragma clang fp contract(off)
 __device__ __forceinline__ double grp_sum8(double v) {
     v += dpp_move(v, 0);     // quad_perm [1,0,3,2]
     v += dpp_move(v, 1);     // quad_perm [2,3,0,1]
     v += dpp_move(v, 2);     // row_half_mirror: lane i <-> 7-i of its 8-lane half row
     return v;
 }
+#pragma clang fp contract(fast)
 
 // sinh-arcsinh helpers (klhr_sinh.py:78-84): s = exp(clip(eta1)) + tol, d = exp(clip(eta2)) + tol
 // sub == true: SUBKLHRSINH's 3-parameter form, d == 1 and e = eta[2] (sub_klhr_sinh.py:92-97)
@@ -493,6 +498,11 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
                         opt_cache_store(o, f, g);
                         dg_pass++;
                     }
+#ifdef KLHR_FIT_PRINTF
+                    if (c == 0 && l8 == 0 && o.n != 1)
+                        printf("pass %d pc %d x %.17g %.17g %.17g %.17g f %.17g g %.17g %.17g %.17g %.17g oldf %.17g\n", dg_pass, (int)o.pc,
+                               o.xt[0], o.xt[1], o.xt[2], o.xt[3], f, g[0], g[1], g[2], g[3], o.old_fval);
+#endif
                     KLHR_STAMP(st_eval);
 #ifdef KLHR_OCTET_OUTLINE
                     opt_advance<true>(o, f, g);

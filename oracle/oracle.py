@@ -13,7 +13,7 @@ from numpy.polynomial.hermite import hermgauss
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libklhr_oracle.so")
 
-MODEL_IDS = {"funnel": 0, "ill-normal": 1, "glmm-poisson": 2, "normal": 3}
+MODEL_IDS = {"funnel": 0, "ill-normal": 1, "glmm-poisson": 2, "normal": 3, "ar1": 4, "earnings": 5}
 
 F = dict(theta=0, rng=1, mean=2, cov=3, eigvecs=4, eigvals=5, om_m=6, om_v=7, om_N=8, omd_m=9, omd_v=10, omd_N=11,
          pca_v=12, pca_n=13, draw=14, acc=15, grad_evals=16, rho=17, eta=18, diag=19, cidx=20, prev_theta=21)
@@ -106,6 +106,10 @@ def model_data(stem, data):
         return np.array([float(data["D"])])
     if stem == "glmm-poisson":
         return np.concatenate([[float(data["n"])], np.asarray(data["year"], float), np.asarray(data["C"], float)])
+    if stem == "ar1":
+        return np.array([float(data["N"])])
+    if stem == "earnings":
+        return np.concatenate([[float(data["N"])], np.asarray(data["earn"], float), np.asarray(data["height"], float)])
     raise KeyError(stem)
 
 
@@ -251,7 +255,8 @@ def KLHRChain(stem, data, seed=None, **kw):
     """A chain of the Gaussian-proposal sampler with klhr.py's constructor defaults (klhr.py:16-34)."""
     d = dict(tol=1e-12, scale_clip=600, overrelaxed=False, eigen_method_one=True, variant="gauss")
     d.update(kw)
-    D = {"funnel": lambda: data["D"] + 1, "glmm-poisson": lambda: data["n"] + 5}.get(stem, lambda: data["D"])()
+    D = {"funnel": lambda: data["D"] + 1, "glmm-poisson": lambda: data["n"] + 5, "ar1": lambda: data["N"],
+         "earnings": lambda: 4}.get(stem, lambda: data["D"])()
     d["J"] = min(d.get("J", 2), D - 1)          # klhr.py:39
     return Chain(stem, data, seed=seed, **d)
 

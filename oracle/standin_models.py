@@ -141,6 +141,75 @@ class GlmmPoisson(_Base):
         return lp, g
 
 
+class AR1(_Base):
+    """stan/ar1.stan:1-14: y_1 ~ N(0,1), y_i ~ N(alpha y_{i-1}, beta), alpha = 0.9, beta = sqrt(1 - alpha^2)"""
+    name = "ar1"
+
+    def __init__(self, N):
+        self.D = int(N)
+        self.alpha = 0.9
+        self.beta = np.sqrt(1 - self.alpha * self.alpha)
+
+    def data(self):
+        return np.array([float(self.D)])
+
+    def log_density_gradient(self, theta, **kws):
+        y = np.asarray(theta, dtype=np.float64)
+        D, a, b = self.D, self.alpha, self.beta
+        g = np.zeros(D)
+        lp = -0.5 * y[0] * y[0]
+        g[0] = -y[0]
+        for i in range(1, D):
+            z = (y[i] - a * y[i - 1]) / b
+            lp -= 0.5 * z * z
+            g[i] = -z / b
+            g[i - 1] += a * z / b
+        return lp, g
+
+
+class Earnings(_Base):
+    """stan/earnings.stan:1-17 on the unconstrained scale theta = (beta_1, beta_2, log sigma, log s); the Gaussian
+    likelihood is evaluated through centred sufficient statistics (exact algebra, numerically stable)."""
+    name = "earnings"
+
+    def __init__(self, earn, height):
+        e = np.asarray(earn, dtype=np.float64)
+        h = np.asarray(height, dtype=np.float64)
+        self.D = 4
+        self.N = float(e.size)
+        self.ebar, self.hbar = e.mean(), h.mean()
+        ec, hc = e - self.ebar, h - self.hbar
+        self.See, self.Seh, self.Shh = float(ec @ ec), float(ec @ hc), float(hc @ hc)
+        self._raw = np.concatenate([[self.N], e, h])
+
+    def data(self):
+        return self._raw
+
+    def stats(self):
+        return np.array([self.N, self.ebar, self.hbar, self.See, self.Seh, self.Shh])
+
+    def log_density_gradient(self, theta, **kws):
+        th = np.asarray(theta, dtype=np.float64)
+        b1, b2, lsig, ls = th
+        sigma, s = np.exp(lsig), np.exp(ls)
+        N = self.N
+        delta = self.ebar - b1 - b2 * self.hbar
+        SS = self.See - 2 * b2 * self.Seh + b2 * b2 * self.Shh + N * delta * delta
+        q1, q2 = b1 * b1 / (5 * s * s), b2 * b2 / (5 * s * s)
+        lp = -0.01 * s + ls
+        lp += -3 * np.log1p(q1) - ls
+        lp += -3 * np.log1p(q2) - ls
+        lp += -0.1 * sigma + lsig
+        lp += -N * lsig - SS / (2 * sigma * sigma)
+        g = np.zeros(4)
+        i2 = 1 / (sigma * sigma)
+        g[0] = -6 * b1 / (5 * s * s + b1 * b1) + N * delta * i2
+        g[1] = -6 * b2 / (5 * s * s + b2 * b2) + (self.Seh - b2 * self.Shh + N * delta * self.hbar) * i2
+        g[2] = -0.1 * sigma + 1 - N + SS * i2
+        g[3] = -0.01 * s + 1 + (6 * q1 / (1 + q1) - 1) + (6 * q2 / (1 + q2) - 1)
+        return lp, g
+
+
 def from_files(stem, data):
     """Build a stand-in from a Stan program stem + parsed JSON data dict."""
     if stem == "funnel":
@@ -151,6 +220,10 @@ def from_files(stem, data):
         return Normal(data["D"])
     if stem == "glmm-poisson":
         return GlmmPoisson(data["year"], data["C"])
+    if stem == "ar1":
+        return AR1(data["N"])
+    if stem == "earnings":
+        return Earnings(data["earn"], data["height"])
     raise KeyError(stem)
 
 

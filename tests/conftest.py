@@ -33,6 +33,11 @@ def model_spec(name):
         return "normal", {"D": 2}
     if name == "normal100":
         return "normal", {"D": 100}
+    if name == "ar1x100":
+        return "ar1", {"N": 100}
+    if name == "earnings":
+        with open(os.path.join(STAN, "earnings.json")) as f:
+            return "earnings", json.load(f)
     if name == "glmm45":
         with open(os.path.join(STAN, "glmm-poisson.json")) as f:
             return "glmm-poisson", json.load(f)

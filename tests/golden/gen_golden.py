@@ -72,6 +72,12 @@ def make_model(name):
     if name == "glmm45":
         d = glmm_data()
         return sm.GlmmPoisson(d["year"], d["C"])
+    if name == "ar1x100":
+        return sm.AR1(100)
+    if name == "earnings":
+        with open(os.path.join(ROOT, "klhr_amd", "stan", "earnings.json")) as f:
+            d = json.load(f)
+        return sm.Earnings(d["earn"], d["height"])
     if name == "normal2":
         return sm.Normal(2)
     if name == "normal100":
@@ -183,7 +189,7 @@ def g3_primitives():
 
 def g4_kl():
     out = {}
-    for name in ["funnel10", "illnormal100", "glmm45", "normal2", "funnel100"]:
+    for name in ["funnel10", "illnormal100", "glmm45", "normal2", "funnel100", "ar1x100", "earnings"]:
         model = make_model(name)
         a = ref_klhr_sinh.KLHRSINH(model, seed=11, overrelaxed=False)
         D = a.D
@@ -197,6 +203,9 @@ def g4_kl():
         if name.startswith("funnel"):
             thetas[5, 0] = -9.0            # narrow neck: huge gradients -> clip
             thetas[6, 0] = 7.0
+        if name == "earnings":             # half of the points near the posterior mode, half near the 0.1*N(0,1) start
+            thetas[::2] = np.array([-6e4, 1.25e3, 9.85, 7.0]) + g.normal(size=(n // 2, 4)) * np.array([3e3, 40.0, 0.05, 0.5])
+            etas[:, 1] += np.where(np.arange(n) % 2 == 0, 5.0, 0.0)
         vals = np.zeros(n)
         grads = np.zeros((n, 4))
         lps = np.zeros(n)
@@ -493,6 +502,8 @@ def g8_chains():
     jobs.append(("funnel10", 5, 200, 100, {"eigen_method_one": True}))
     jobs.append(("funnel10", 6, 200, 100, {"scale_dir_cov": True}))
     jobs.append(("funnel10", 7, 400, 1000, {}))     # constructor-default warmup: closures 50,150,350,1000
+    jobs.append(("ar1x100", 0, 130, 100, {}))
+    jobs.append(("earnings", 0, 200, 100, {}))
     for name, seed, M, warmup, flags in jobs:
         tag = "".join(k[0] for k in sorted(flags))  # "", "e", "s"
         fn = os.path.join(HERE, f"g8_{name}_s{seed}_w{warmup}{('_' + tag) if tag else ''}.npz")

@@ -41,7 +41,7 @@ def test_primitives_grid(oracle):
             assert close(p["log_q"], g["log_q"][i, j], rtol=1e-11, atol=1e-11), (i, j)
 
 
-@pytest.mark.parametrize("name", ["funnel10", "illnormal100", "glmm45", "normal2", "funnel100"])
+@pytest.mark.parametrize("name", ["funnel10", "illnormal100", "glmm45", "normal2", "funnel100", "ar1x100", "earnings"])
 def test_kl_and_models(oracle, name):
     g = golden("g4_kl.npz")
     stem, data = model_spec(name)
@@ -61,7 +61,7 @@ def test_kl_and_models(oracle, name):
         assert close([f, df], g[f"{name}_line"][i], atol=1e-12 * max(1.0, np.abs(g[f"{name}_line"][i]).max())), i
 
 
-@pytest.mark.parametrize("name", ["funnel10", "illnormal100", "glmm45", "normal2"])
+@pytest.mark.parametrize("name", ["funnel10", "illnormal100", "glmm45", "normal2", "ar1x100"])
 def test_model_gradients_finite_difference(oracle, name):
     """The closed forms stand in for BridgeStan (parity unpinned there): at least d/dtheta is self-consistent."""
     stem, data = model_spec(name)
