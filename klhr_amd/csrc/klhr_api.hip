@@ -235,10 +235,10 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
     int SL = 3 * D;
     while (SL % 32 != 2) SL++;
     s->S_lane = SL;
-    s->use_lane = (D <= 26) && ((size_t)64 * SL * 8 <= 64 * 1024);
+    s->use_lane = (D <= 26) && (((size_t)64 * SL + 624) * 8 <= 64 * 1024);   // + LANE_LDS_EXTRA (klhr_lane_kernel.hpp)
     if (const char *kk = getenv("KLHR_KERNEL")) {
         if (!strcmp(kk, "octet")) s->use_lane = false;
-        else if (!strcmp(kk, "lane") && (size_t)64 * SL * 8 <= 64 * 1024) s->use_lane = true;
+        else if (!strcmp(kk, "lane") && ((size_t)64 * SL + 624) * 8 <= 64 * 1024) s->use_lane = true;
     }
     auto bail = [&](int rc) { g_create_err = s->err; klhr_destroy(s); return rc; };
     {

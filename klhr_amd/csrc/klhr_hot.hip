@@ -19,7 +19,7 @@ void KLHR_CAT(launch_hot_v, KLHR_VARIANT, _o, KLHR_OVERRELAX)(const KParams &kp,
     constexpr bool O = KLHR_OVERRELAX != 0;
     if (lane) {
         const dim3 grid((kp.C + 63) / 64), block(64);
-        const size_t lds = (size_t)64 * kp.S * sizeof(double);
+        const size_t lds = ((size_t)64 * kp.S + LANE_LDS_EXTRA) * sizeof(double);
         switch (model_id) {
         case KLHR_MODEL_FUNNEL: hipLaunchKernelGGL((klhr_lane_kernel<MODEL_FUNNEL, O, V>), grid, block, lds, stream, kp); break;
         case KLHR_MODEL_ILL_NORMAL: hipLaunchKernelGGL((klhr_lane_kernel<MODEL_ILL_NORMAL, O, V>), grid, block, lds, stream, kp); break;

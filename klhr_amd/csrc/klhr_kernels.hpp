@@ -184,6 +184,7 @@ __device__ __forceinline__ void smoother_update(double &x, double &count, bool m
 
 // log(cosh(a)) from m = exp(-|a|): |a| - ln 2 + log1p(m^2), log1p(u) = 2 atanh(u/(2+u)) by its odd series (s <= 1/3,
 // truncation < 2e-18).  Absolute error ~2e-16, at ~40 instead of ~100 instructions for log(cosh(.)).
+#pragma clang fp contract(off)   // explicit fma only: rounds identically wherever it is inlined
 __device__ __forceinline__ double log_cosh_from_exp(double absa, double m) {
     const double u = m * m;
     const double s = u / (2.0 + u);
@@ -197,6 +198,7 @@ __device__ __forceinline__ double log_cosh_from_exp(double absa, double m) {
     const double lp = 2.0 * s * q;
     return absa + (lp - 0.6931471805599453094);
 }
+#pragma clang fp contract(fast)
 
 template <int MODEL, int VARIANT>
 __device__ __forceinline__ void eval_objective(const KParams &p, const double2 *TR, int n, const double *xt, double asx_l,

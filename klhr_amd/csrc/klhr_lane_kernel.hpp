@@ -148,55 +148,96 @@ __device__ inline void lane_close_window(const KParams &p, long long c, long lon
 }
 #pragma clang fp contract(fast)
 
-// KL(eta) value + gradient for this lane's chain (klhr_sinh.py:163-176, nodes accumulated in reference order).
-// The 8 nodes are processed as 8/NVG groups of NVG register-resident accumulator chains.
+// KL(eta) value + gradient (klhr_sinh.py:163-176) as a sum over *node groups*.
+//
+// The 8 quadrature nodes are processed in groups of G in {4, 2, 1} register-resident accumulator chains
+// (model_eval_nv<MODEL, G>); a group returns the partial sums (KL, dKL/deta0..3) of its nodes, and partials are combined
+// in one fixed binary tree over the node index, ((0+1)+(2+3))+((4+5)+(6+7)).  Because of that fixed tree — and because
+// every per-node quantity is computed by the same (unfused or explicitly fused) instruction sequence whatever G is —
+// the result does not depend on *who* evaluates a group: the chain's own lane (two groups of 4, the normal case), or
+// idle lanes of the wavefront on its behalf (node-shared evaluation in the fit loop below).
 #ifndef KLHR_NVG
 #define KLHR_NVG 4
 #endif
 
+// extra LDS behind the 64 chain regions (doubles): published trial points [64][4], group partials [64][5],
+// owner table [64] ints, quadrature table asinh(x)[8], w[8]
+constexpr int LANE_XT = 0, LANE_PART = 256, LANE_OWN = 576, LANE_Q = 608, LANE_LDS_EXTRA = 624;
+
+struct KLScal { double s_, invd, e21, esh; };
+
+// per-evaluation scalars of the sinh-arcsinh family; SUB: d == 1, e = x2 (sub_klhr_sinh.py:92-97)
+template <bool SUB>
+__device__ __forceinline__ KLScal kl_scalars(const KParams &p, double x1, double x2, double x3) {
+    KLScal k;
+    k.s_ = exp(clipc(x1, p.scale_clip)) + p.tol;
+    k.invd = SUB ? 1.0 : 1.0 / (exp(clipc(x2, p.scale_clip)) + p.tol);
+    k.e21 = SUB ? -x1 : x2 - x1;
+    k.esh = SUB ? x2 : x3;
+    return k;
+}
+
+#pragma clang fp contract(off)
+// contribution of one node to (KL, dKL/deta): explicit operations only, so every instantiation rounds identically
+template <bool SUB>
+__device__ __forceinline__ void kl_node_terms(double w, double a, double sh, double ch, double lch, double logp, double gdot,
+                                              const KLScal &k, double (&c)[5]) {
+    const double th = sh / ch;
+    const double laj = k.e21 - lch;
+    c[0] = w * (laj - logp);
+    const double wg = w * gdot;
+    c[1] = -wg;
+    c[2] = -fma(wg, k.s_ * sh, w);
+    const double sc = k.s_ * ch;
+    if (SUB) { c[3] = -fma(wg, sc, w * th); c[4] = 0.0; }
+    else {
+        c[3] = fma(wg, sc * a, w * fma(th, a, 1.0));
+        c[4] = -fma(wg, sc * k.invd, w * (th * k.invd));
+    }
+}
+
+// partial sums of nodes n0 .. n0+G-1 for the chain whose (theta, rho) pairs sit at TR; asx / wq point at the group's
+// first node (kernel-argument tables on the normal path, the LDS copy when n0 is a per-lane value)
+template <int MODEL, bool SUB, int G>
+__device__ __forceinline__ void lane_kl_group(const KParams &p, const double2 *TR, double x0, const KLScal &k, const double *asx,
+                                              const double *wq, double (&part)[5]) {
+    double sh[G], ch[G], lch[G], t[G], av[G], logp[G], gdot[G];
+#pragma unroll
+    for (int n = 0; n < G; n++) {
+        const double a = (asx[n] + k.esh) * k.invd;
+        const double ac = clipc(a, p.scale_clip);
+        // one exp serves sinh and cosh: |abs error| <= 2^-53 * cosh, the same size as the rounding of the sums
+        // these values enter (KL value/gradient stay within the 1e-12 parity bound, tests/test_gpu_parity.py)
+        const double E = exp(ac), Ei = 1.0 / E;
+        sh[n] = 0.5 * (E - Ei);
+        ch[n] = 0.5 * (E + Ei);
+        lch[n] = log_cosh_from_exp(fabs(ac), fmin(E, Ei));
+        t[n] = fma(k.s_, sh[n], x0);
+        av[n] = a;
+    }
+    model_eval_nv<MODEL, G>(p.md, TR, t, SUB ? p.grad_clip : p.scale_clip, logp, gdot);
+    double c[G][5];
+#pragma unroll
+    for (int n = 0; n < G; n++) kl_node_terms<SUB>(wq[n], av[n], sh[n], ch[n], lch[n], logp[n], gdot[n], k, c[n]);
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        if constexpr (G == 4) part[j] = (c[0][j] + c[1][j]) + (c[2][j] + c[3][j]);
+        else if constexpr (G == 2) part[j] = c[0][j] + c[1][j];
+        else part[j] = c[0][j];
+    }
+}
+#pragma clang fp contract(fast)
+
+// whole evaluation by the chain's own lane (probes; the fit loop inlines the same two groups)
 template <int MODEL, bool SUB = false>
 __device__ __forceinline__ void lane_eval_kl(const KParams &p, const double2 *TR, const double *xt, double &f, double *g) {
-    constexpr int NVG = KLHR_NVG;
-    // SUB: SUBKLHRSINH's 3-parameter proposal (sub_klhr_sinh.py): d == 1, e = xt[2], gradient clipped at grad_clip
-    const double s_ = exp(clipc(xt[1], p.scale_clip)) + p.tol;
-    const double invd = SUB ? 1.0 : 1.0 / (exp(clipc(xt[2], p.scale_clip)) + p.tol);
-    const double e21 = SUB ? -xt[1] : xt[2] - xt[1];
-    const double esh = SUB ? xt[2] : xt[3];
-    double out = 0.0, g0 = 0.0, g1 = 0.0, g2 = 0.0, g3 = 0.0;
+    const KLScal k = kl_scalars<SUB>(p, xt[1], xt[2], xt[3]);
+    double P0[5], P1[5];
+    lane_kl_group<MODEL, SUB, 4>(p, TR, xt[0], k, p.asx, p.wq, P0);
+    lane_kl_group<MODEL, SUB, 4>(p, TR, xt[0], k, p.asx + 4, p.wq + 4, P1);
+    f = __dadd_rn(P0[0], P1[0]);
 #pragma unroll
-    for (int h = 0; h < 8 / NVG; h++) {
-        double sh[NVG], ch[NVG], lch[NVG], t[NVG], logp[NVG], gdot[NVG];
-#pragma unroll
-        for (int n = 0; n < NVG; n++) {
-            const double a = (p.asx[h * NVG + n] + esh) * invd;
-            const double ac = clipc(a, p.scale_clip);
-            // one exp serves sinh and cosh: |abs error| <= 2^-53 * cosh, the same size as the rounding of the sums
-            // these values enter (KL value/gradient stay within the 1e-12 parity bound, tests/test_gpu_parity.py)
-            const double E = exp(ac), Ei = 1.0 / E;
-            sh[n] = 0.5 * (E - Ei);
-            ch[n] = 0.5 * (E + Ei);
-            lch[n] = log_cosh_from_exp(fabs(ac), fmin(E, Ei));
-            t[n] = xt[0] + s_ * sh[n];
-        }
-        model_eval_nv<MODEL, NVG>(p.md, TR, t, SUB ? p.grad_clip : p.scale_clip, logp, gdot);
-#pragma unroll
-        for (int n = 0; n < NVG; n++) {
-            const double w = p.wq[h * NVG + n];
-            const double a = (p.asx[h * NVG + n] + esh) * invd;
-            const double th = sh[n] / ch[n];
-            const double laj = e21 - lch[n];
-            out += w * (laj - logp[n]);
-            const double wg = w * gdot[n];
-            g0 -= wg;
-            g1 -= wg * (s_ * sh[n]);             g1 += w * -1.0;
-            if (SUB) { g2 -= wg * (s_ * ch[n]);      g2 += w * (-th); }
-            else {
-                g2 -= wg * (-s_ * ch[n] * a);    g2 += w * (1.0 + th * a);
-                g3 -= wg * (s_ * ch[n] * invd);  g3 += w * (-th * invd);
-            }
-        }
-    }
-    f = out; g[0] = g0; g[1] = g1; g[2] = g2; g[3] = g3;
+    for (int j = 0; j < 4; j++) g[j] = __dadd_rn(P0[j + 1], P1[j + 1]);
 }
 
 // KLHR objective (klhr.py:109-124) for this lane's chain: 8 nodes y_n = s x_n + m, raw gradient
@@ -246,6 +287,8 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
     const int D = p.D;
     double2 *TR = reinterpret_cast<double2 *>(lds + (size_t)lane * p.S);
     double *Z = lds + (size_t)lane * p.S + 2 * (size_t)D;
+    double *shx = lds + (size_t)64 * p.S;            // node-shared evaluation: see the fit loop
+    if (lane < 8) { shx[LANE_Q + lane] = p.asx[lane]; shx[LANE_Q + 8 + lane] = p.wq[lane]; }
 
     // ---- cooperative, coalesced load of the block's theta rows into LDS
     {
@@ -325,9 +368,68 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
                 const bool ev1 = !done && !hit && o.n == 1;
                 const bool ev4 = !done && !hit && o.n != 1;
                 if (ev1) lane_eval_line<MODEL>(p, TR, o.xt[0], f, g);
-                if (ev4) {
-                    if constexpr (VARIANT == VAR_GAUSS) lane_eval_kl_gauss<MODEL>(p, TR, o.xt, f, g);
-                    else lane_eval_kl<MODEL, VARIANT == VAR_SUB>(p, TR, o.xt, f, g);
+                if constexpr (VARIANT == VAR_GAUSS) {
+                    if (ev4) lane_eval_kl_gauss<MODEL>(p, TR, o.xt, f, g);
+                } else {
+                    // ---- KL evaluation, node-shared when at most half of the lanes need one.
+                    // Chains finish their fits after different numbers of evaluations (mean ~20 passes, slowest of 64
+                    // ~30), so in the second half of a fit most lanes idle.  With n4 <= 64/F requesting chains
+                    // (F = 2, 4, 8) each request is served by F lanes: lane j evaluates the group of 8/F nodes
+                    // number j % F of the chain ranked j / F among the requesters, reading that chain's (theta, rho)
+                    // from its LDS region, and the owner adds the F partials in the fixed tree of lane_kl_group.
+                    constexpr bool SUB = VARIANT == VAR_SUB;
+                    const unsigned long long m4 = __ballot(ev4);
+                    const int n4 = __popcll(m4);
+                    if (n4 > 32) {
+                        if (ev4) {
+                            const KLScal k = kl_scalars<SUB>(p, o.xt[1], o.xt[2], o.xt[3]);
+                            double acc5[5] = {0, 0, 0, 0, 0};
+#pragma unroll 1
+                            for (int h = 0; h < 2; h++) {
+                                double part[5];
+                                lane_kl_group<MODEL, SUB, 4>(p, TR, o.xt[0], k, shx + LANE_Q + 4 * h, shx + LANE_Q + 8 + 4 * h, part);
+#pragma unroll
+                                for (int j = 0; j < 5; j++) acc5[j] = h == 0 ? part[j] : __dadd_rn(acc5[j], part[j]);
+                            }
+                            f = acc5[0]; g[0] = acc5[1]; g[1] = acc5[2]; g[2] = acc5[3]; g[3] = acc5[4];
+                        }
+                    } else if (n4 > 0) {
+                        const int lg = n4 <= 8 ? 3 : (n4 <= 16 ? 2 : 1);
+                        const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m4 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m4, 0u));
+                        if (ev4) {
+                            reinterpret_cast<int *>(shx + LANE_OWN)[rank] = lane;
+#pragma unroll
+                            for (int j = 0; j < 4; j++) shx[LANE_XT + lane * 4 + j] = o.xt[j];
+                        }
+                        KLHR_WAVE_SYNC();
+                        const int r = lane >> lg, sub = lane & ((1 << lg) - 1);
+                        if (r < n4) {
+                            const int ow = reinterpret_cast<const int *>(shx + LANE_OWN)[r];
+                            const double x0 = shx[LANE_XT + ow * 4], x1 = shx[LANE_XT + ow * 4 + 1], x2 = shx[LANE_XT + ow * 4 + 2],
+                                         x3 = shx[LANE_XT + ow * 4 + 3];
+                            const KLScal k = kl_scalars<SUB>(p, x1, x2, x3);
+                            const double2 *TRo = reinterpret_cast<const double2 *>(lds + (size_t)ow * p.S);
+                            double part[5];
+                            if (lg == 3) lane_kl_group<MODEL, SUB, 1>(p, TRo, x0, k, shx + LANE_Q + sub, shx + LANE_Q + 8 + sub, part);
+                            else if (lg == 2) lane_kl_group<MODEL, SUB, 2>(p, TRo, x0, k, shx + LANE_Q + 2 * sub, shx + LANE_Q + 8 + 2 * sub, part);
+                            else lane_kl_group<MODEL, SUB, 4>(p, TRo, x0, k, shx + LANE_Q + 4 * sub, shx + LANE_Q + 8 + 4 * sub, part);
+#pragma unroll
+                            for (int j = 0; j < 5; j++) shx[LANE_PART + lane * 5 + j] = part[j];
+                        }
+                        KLHR_WAVE_SYNC();
+                        if (ev4) {
+                            const double *pp = shx + LANE_PART + (rank << lg) * 5;
+                            double r5[5];
+#pragma unroll
+                            for (int j = 0; j < 5; j++) {
+                                if (lg == 1) r5[j] = __dadd_rn(pp[j], pp[5 + j]);
+                                else if (lg == 2) r5[j] = __dadd_rn(__dadd_rn(pp[j], pp[5 + j]), __dadd_rn(pp[10 + j], pp[15 + j]));
+                                else r5[j] = __dadd_rn(__dadd_rn(__dadd_rn(pp[j], pp[5 + j]), __dadd_rn(pp[10 + j], pp[15 + j])),
+                                                       __dadd_rn(__dadd_rn(pp[20 + j], pp[25 + j]), __dadd_rn(pp[30 + j], pp[35 + j])));
+                            }
+                            f = r5[0]; g[0] = r5[1]; g[1] = r5[2]; g[2] = r5[3]; g[3] = r5[4];
+                        }
+                    }
                 }
                 if (!done) {
                     if (hit) { f = o.lf; g[0] = o.lg[0]; g[1] = o.lg[1]; g[2] = o.lg[2]; g[3] = o.lg[3]; }

@@ -151,7 +151,7 @@ def test_teacher_forced_pieces_vs_oracle(oracle, fn):
     #  coordinates: on both more fits sit on a Wolfe / termination decision boundary and stop one evaluation apart —
     #  the same spread the reference shows against the CPU oracle in tests/test_oracle_chain.py.  Those records must
     #  still reach the same KL value.)
-    need = {"ar1": 0.93, "earnings": 0.95}.get(R["stem"], 0.99)
+    need = {"ar1": 0.95, "earnings": 0.95}.get(R["stem"], 0.99)
     if conv.sum() > 20:
         assert (same & conv).sum() >= need * conv.sum(), ((same & conv).sum(), conv.sum())
     off = conv & ~same
@@ -162,7 +162,7 @@ def test_teacher_forced_pieces_vs_oracle(oracle, fn):
             np.abs(d[off, col["fun2"]] - o_f2[off]).max()
     sel = same & conv
     err = np.abs(eta - R["eta"]) / (1.0 + np.abs(R["eta"]))
-    assert np.all(err[sel] < (5e-5 if R["stem"] == "earnings" else 2e-6)), err[sel].max()
+    assert np.all(err[sel] < 2e-6), err[sel].max()
     assert np.all(d[sel, col["status1"]] == 0) and np.all(d[sel, col["status2"]] == 0)
     # Fits that end in a failed line search (status 2; the norm on glmm-poisson, where the +-300 gradient clip makes
     # the gradient inconsistent with the objective) stop at rounding-noise level: WHICH iterate is the last one is
@@ -174,8 +174,8 @@ def test_teacher_forced_pieces_vs_oracle(oracle, fn):
             frel = np.abs(d[fl, col["fun2"]] - o_fun2[fl]) / (1.0 + np.abs(o_fun2[fl]))
         # (wolfe2 can accept a step whose f is NaN when only the derivative test holds — SciPy then stops with
         #  status 2 and fun = NaN; whether that happens is again decided by rounding, so allow it in <= 2 % of records)
-        assert np.mean(np.nan_to_num(frel, nan=1.0) < 1e-5) >= 0.98, np.sort(frel)[-5:]
-        assert np.mean(err[fl].max(axis=1) < 1e-5) >= 0.75, np.sort(err[fl].max(axis=1))[-5:]
+        assert np.mean(np.nan_to_num(frel, nan=1.0) < 1e-7) >= 0.98, np.sort(frel)[-5:]
+        assert np.mean(err[fl].max(axis=1) < 1e-5) >= 0.95, np.sort(err[fl].max(axis=1))[-5:]
     # grad_evals bookkeeping (klhr_sinh.py:188,200)
     ge = s.get("grad_evals")
     assert np.array_equal(ge - np.asarray(R["gev_before"], dtype=np.int64), (d[:, col["nfev1"]] + 8 * d[:, col["nfev2"]]).astype(np.int64))

@@ -3,8 +3,9 @@ import os, sys
 ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,ROOT)
 import numpy as np
 from klhr_amd import _lib
-C=65536
-s=_lib.Sampler(_lib.MODEL_IDS["funnel"],np.array([9.0]),C,warmup=100)
+model=sys.argv[1] if len(sys.argv)>1 else "funnel"; D=int(sys.argv[2]) if len(sys.argv)>2 else 10; C=int(sys.argv[3]) if len(sys.argv)>3 else 65536
+data=np.array([D-1.0]) if model=="funnel" else np.array([float(D)])
+s=_lib.Sampler(_lib.MODEL_IDS[model],data,C,warmup=100)
 s.seed(np.arange(C,dtype=np.uint64))
 s.step(50); s.step(50); s.step(20)          # dispatches 1-3 (iter kernels)
 rho=s.random_direction()                    # 4: direction
