@@ -19,13 +19,22 @@
 namespace klhr {
 
 #pragma clang fp contract(off)
+// Lane-private rows of the chain state live in HBM ([chain][i] layout) and a wavefront alone on its SIMD has nothing
+// to hide a load's latency behind, so rows are fetched in chunks of LANE_CH elements — all loads of a chunk in flight
+// at once — into registers, worked on there, and stored back.  Arithmetic and its order are unchanged.
+constexpr int LANE_CH = 13;        // the lane kernel serves D <= 26 (klhr_api.hip): two chunks
+
+template <class T>
+__device__ __forceinline__ void lane_load_chunk(const T *src, int stride, int i0, int D, T (&r)[LANE_CH]) {
+#pragma unroll
+    for (int k = 0; k < LANE_CH; k++) { const int i = i0 + k < D ? i0 + k : D - 1; r[k] = src[(long long)i * stride]; }
+}
+
 // klhr_sinh.py:203-213 for the chain owned by this lane (sequential, unfused: rounds like NumPy)
 __device__ inline void lane_direction(const KParams &p, long long c, double2 *TR, const double *Z, double u_choice) {
     const int D = p.D, nc = p.ncol;
     const double *ev = p.eigvals + c * nc;
     const double *evec = p.eigvecs + c * (long long)D * nc;
-    const double *cov = p.cov + c * (long long)D;
-    const int *rank = p.rank + c * (long long)D;
     double pj[4] = {0, 0, 0, 0};
     double sum = 0;
 #pragma unroll
@@ -43,19 +52,31 @@ __device__ inline void lane_direction(const KParams &p, long long c, double2 *TR
         if (pick >= nc) pick = nc - 1;
     }
     double nn = 0;
-    for (int i = 0; i < D; i++) {
-        double m = 0;
+    for (int i0 = 0; i0 < D; i0 += LANE_CH) {
+        double e0[LANE_CH], e1[LANE_CH], cv[LANE_CH];
+        int rk[LANE_CH];
+        lane_load_chunk(evec, nc, i0, D, e0);
+        if (nc > 1) lane_load_chunk(evec + 1, nc, i0, D, e1);
+        lane_load_chunk(p.cov + c * (long long)D, 1, i0, D, cv);
+        lane_load_chunk(p.rank + c * (long long)D, 1, i0, D, rk);
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (j < nc) {
-                double e = evec[i * nc + j];
-                if (pick >= 0) { if (j == pick) m = e; }
-                else m += (p.variant == VAR_GAUSS ? ev[j] : pj[j]) * e;      // klhr.py:150
+        for (int k = 0; k < LANE_CH; k++) {
+            const int i = i0 + k;
+            if (i < D) {
+                double m = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (j < nc) {
+                        double e = j == 0 ? e0[k] : (j == 1 ? e1[k] : evec[i * nc + j]);
+                        if (pick >= 0) { if (j == pick) m = e; }
+                        else m += (p.variant == VAR_GAUSS ? ev[j] : pj[j]) * e;      // klhr.py:150
+                    }
+                }
+                double r = m + sqrt(cv[k]) * Z[rk[k]];
+                nn += (r + p.tol) * (r + p.tol);
+                TR[i].y = r;
             }
         }
-        double r = m + sqrt(cov[i]) * Z[rank[i]];
-        nn += (r + p.tol) * (r + p.tol);
-        TR[i].y = r;
     }
     nn = sqrt(nn);
     for (int i = 0; i < D; i++) TR[i].y = TR[i].y / nn;
@@ -64,18 +85,28 @@ __device__ inline void lane_direction(const KParams &p, long long c, double2 *TR
 // onlinemoments.py:10-18
 __device__ inline void lane_om_update(double *m, double *v, long long N, int D, const double2 *TR, const double *Z, bool fromZ, double clipb) {
     const double w = 1.0 / (double)N;
-    for (int i = 0; i < D; i++) {
-        double x = fromZ ? clipc(Z[i], clipb) : TR[i].x;
-        double mi = m[i], vi = v[i];
-        double d = x - mi;
-        mi += d * w;
-        vi += -vi * w + d * d * w * (1 - w);
-        m[i] = mi;
-        v[i] = vi;
+    for (int i0 = 0; i0 < D; i0 += LANE_CH) {
+        double mr[LANE_CH], vr[LANE_CH];
+        lane_load_chunk(m, 1, i0, D, mr);
+        lane_load_chunk(v, 1, i0, D, vr);
+#pragma unroll
+        for (int k = 0; k < LANE_CH; k++) {
+            const int i = i0 + k;
+            if (i < D) {
+                double x = fromZ ? clipc(Z[i], clipb) : TR[i].x;
+                double mi = mr[k], vi = vr[k];
+                double d = x - mi;
+                mi += d * w;
+                vi += -vi * w + d * d * w * (1 - w);
+                m[i] = mi;
+                v[i] = vi;
+            }
+        }
     }
 }
 
-// onlinepca.py:13-26; u = theta - mean in Z (LDS, lane-private), V rows in HBM (lane-private)
+// onlinepca.py:13-26; u = theta - mean in Z (LDS, lane-private), V rows in HBM (lane-private).  The column is held in
+// registers (two chunks) across the three passes over it.
 __device__ inline void lane_pca_update(const KParams &p, long long c, long long n_new, double *Z) {
     const int D = p.D, K = p.J;
     double *V = p.pca_v + c * (long long)D * K;
@@ -85,16 +116,29 @@ __device__ inline void lane_pca_update(const KParams &p, long long c, long long 
             for (int i = 0; i < D; i++) V[i * K + col] = Z[i];
         } else {
             const double w = ((double)(n_new - 1) - p.l) / (double)n_new;
+            double va[LANE_CH], vb[LANE_CH];
+            lane_load_chunk(V + col, K, 0, D, va);
+            if (D > LANE_CH) lane_load_chunk(V + col, K, LANE_CH, D, vb);
             double s = 0, udv = 0;
-            for (int i = 0; i < D; i++) { double vi = V[i * K + col]; s += vi * vi; }
+#pragma unroll
+            for (int i = 0; i < 2 * LANE_CH; i++) if (i < D) { double vi = i < LANE_CH ? va[i % LANE_CH] : vb[i % LANE_CH]; s += vi * vi; }
             double nv = sqrt(s);
-            for (int i = 0; i < D; i++) udv += Z[i] * V[i * K + col];
-            for (int i = 0; i < D; i++) V[i * K + col] = w * V[i * K + col] + (1 - w) * Z[i] * udv / (nv + PCA_TOL);
+#pragma unroll
+            for (int i = 0; i < 2 * LANE_CH; i++) if (i < D) udv += Z[i] * (i < LANE_CH ? va[i % LANE_CH] : vb[i % LANE_CH]);
+#pragma unroll
+            for (int i = 0; i < 2 * LANE_CH; i++) if (i < D) {
+                double &vr = i < LANE_CH ? va[i % LANE_CH] : vb[i % LANE_CH];
+                vr = w * vr + (1 - w) * Z[i] * udv / (nv + PCA_TOL);
+                V[i * K + col] = vr;
+            }
             s = 0; udv = 0;
-            for (int i = 0; i < D; i++) { double vi = V[i * K + col]; s += vi * vi; }
+#pragma unroll
+            for (int i = 0; i < 2 * LANE_CH; i++) if (i < D) { double vi = i < LANE_CH ? va[i % LANE_CH] : vb[i % LANE_CH]; s += vi * vi; }
             nv = sqrt(s);
-            for (int i = 0; i < D; i++) udv += Z[i] * V[i * K + col];
-            for (int i = 0; i < D; i++) Z[i] = Z[i] - udv * V[i * K + col] / (nv * nv + PCA_TOL);
+#pragma unroll
+            for (int i = 0; i < 2 * LANE_CH; i++) if (i < D) udv += Z[i] * (i < LANE_CH ? va[i % LANE_CH] : vb[i % LANE_CH]);
+#pragma unroll
+            for (int i = 0; i < 2 * LANE_CH; i++) if (i < D) Z[i] = Z[i] - udv * (i < LANE_CH ? va[i % LANE_CH] : vb[i % LANE_CH]) / (nv * nv + PCA_TOL);
         }
     }
 }
@@ -542,8 +586,12 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
                                    VARIANT == VAR_GAUSS ? INFINITY : (VARIANT == VAR_SUB ? p.grad_clip : p.scale_clip));
                 }
                 lane_om_update(p.om_m + c * (long long)D, p.om_v + c * (long long)D, omN, D, TR, Z, false, 0.0);
-                const double *mean = p.mean + c * (long long)D;
-                for (int i = 0; i < D; i++) Z[i] = __dsub_rn(TR[i].x, mean[i]);
+                for (int i0 = 0; i0 < D; i0 += LANE_CH) {
+                    double mr[LANE_CH];
+                    lane_load_chunk(p.mean + c * (long long)D, 1, i0, D, mr);
+#pragma unroll
+                    for (int k = 0; k < LANE_CH; k++) if (i0 + k < D) Z[i0 + k] = __dsub_rn(TR[i0 + k].x, mr[k]);
+                }
                 pcan += 1;
                 lane_pca_update(p, c, pcan, Z);
             }
