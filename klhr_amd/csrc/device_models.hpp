@@ -69,10 +69,10 @@ __device__ __forceinline__ void model_eval(const ModelData &md, XR xr, double cl
                 gd += clipc(gi, cl) * ri;
             }
         }
-        double g0 = -v / 9.0 - 0.5 * Da + 0.5 * ev * ss;
+        double g0 = -v * (1.0 / 9.0) - 0.5 * Da + 0.5 * ev * ss;
         sink(0, g0);
         gdot = clipc(g0, cl) * r0 + gd;
-        logp = -v * v / 18.0 - 0.5 * Da * v - 0.5 * ev * ss;
+        logp = -v * v * (1.0 / 18.0) - 0.5 * Da * v - 0.5 * ev * ss;
     } else if constexpr (MODEL == MODEL_ILL_NORMAL || MODEL == MODEL_NORMAL) {
         double acc = 0.0, gd = 0.0;
         if (std::is_same<SINK, NoSink>::value) {
@@ -151,8 +151,8 @@ __device__ __forceinline__ void model_eval(const ModelData &md, XR xr, double cl
         double alpha, b0, b1, b2, ell, ra, rb0, rb1, rb2, rl;
         xr(0, alpha, ra); xr(1, b0, rb0); xr(2, b1, rb1); xr(3, b2, rb2); xr(4, ell, rl);
         const double sigma = exp(ell);
-        double lp = -alpha * alpha / 50.0;
-        lp -= b0 * b0 / 50.0; lp -= b1 * b1 / 50.0; lp -= b2 * b2 / 50.0;
+        double lp = -alpha * alpha * (1.0 / 50.0);
+        lp -= b0 * b0 * (1.0 / 50.0); lp -= b1 * b1 * (1.0 / 50.0); lp -= b2 * b2 * (1.0 / 50.0);
         lp -= 0.5 * ell * ell;
         double sr = 0, s1 = 0, s2 = 0, s3 = 0, sre = 0, see = 0, lik = 0, gd = 0;
         for (int i = 0; i < n; i++) {
@@ -170,7 +170,7 @@ __device__ __forceinline__ void model_eval(const ModelData &md, XR xr, double cl
             gd += clipc(ge, cl) * re;
         }
         lp += -0.5 * see + lik;
-        double g0 = -alpha / 25.0 + sr, g1 = -b0 / 25.0 + s1, g2 = -b1 / 25.0 + s2, g3 = -b2 / 25.0 + s3;
+        double g0 = -alpha * (1.0 / 25.0) + sr, g1 = -b0 * (1.0 / 25.0) + s1, g2 = -b1 * (1.0 / 25.0) + s2, g3 = -b2 * (1.0 / 25.0) + s3;
         double g4 = -ell + sigma * sre;
         sink(0, g0); sink(1, g1); sink(2, g2); sink(3, g3); sink(4, g4);
         gd += clipc(g0, cl) * ra; gd += clipc(g1, cl) * rb0; gd += clipc(g2, cl) * rb1; gd += clipc(g3, cl) * rb2;
@@ -207,9 +207,9 @@ __device__ __forceinline__ void model_eval_split(const ModelData &md, const doub
         }
         ss = sum8(ss);
         gd = sum8(gd);
-        double g0 = -v / 9.0 - 0.5 * Da + 0.5 * ev * ss;
+        double g0 = -v * (1.0 / 9.0) - 0.5 * Da + 0.5 * ev * ss;
         gdot = clipc(g0, cl) * e0.y + gd;
-        logp = -v * v / 18.0 - 0.5 * Da * v - 0.5 * ev * ss;
+        logp = -v * v * (1.0 / 18.0) - 0.5 * Da * v - 0.5 * ev * ss;
     } else if constexpr (MODEL == MODEL_ILL_NORMAL || MODEL == MODEL_NORMAL) {
         double acc = 0.0, gd = 0.0;
         for (int i = l8; i < D; i += 8) {
@@ -242,11 +242,11 @@ __device__ __forceinline__ void model_eval_split(const ModelData &md, const doub
             gd += clipc(-e + sigma * r, cl) * e2.y;
         }
         sr = sum8(sr); s1 = sum8(s1); s2 = sum8(s2); s3 = sum8(s3); sre = sum8(sre); see = sum8(see); lik = sum8(lik); gd = sum8(gd);
-        double lp = -alpha * alpha / 50.0;
-        lp -= b0 * b0 / 50.0; lp -= b1 * b1 / 50.0; lp -= b2 * b2 / 50.0;
+        double lp = -alpha * alpha * (1.0 / 50.0);
+        lp -= b0 * b0 * (1.0 / 50.0); lp -= b1 * b1 * (1.0 / 50.0); lp -= b2 * b2 * (1.0 / 50.0);
         lp -= 0.5 * ell * ell;
         lp += -0.5 * see + lik;
-        double g0 = -alpha / 25.0 + sr, g1 = -b0 / 25.0 + s1, g2 = -b1 / 25.0 + s2, g3 = -b2 / 25.0 + s3, g4 = -ell + sigma * sre;
+        double g0 = -alpha * (1.0 / 25.0) + sr, g1 = -b0 * (1.0 / 25.0) + s1, g2 = -b1 * (1.0 / 25.0) + s2, g3 = -b2 * (1.0 / 25.0) + s3, g4 = -ell + sigma * sre;
         gd += clipc(g0, cl) * ea.y; gd += clipc(g1, cl) * eb0.y; gd += clipc(g2, cl) * eb1.y; gd += clipc(g3, cl) * eb2.y;
         gd += clipc(g4, cl) * el.y;
         gdot = gd;
@@ -334,9 +334,9 @@ __device__ __forceinline__ void model_eval_nv(const ModelData &md, const double2
         }
 #pragma unroll
         for (int n = 0; n < NV; n++) {
-            double g0 = -v[n] / 9.0 - 0.5 * Da + 0.5 * ev[n] * ss[n];
+            double g0 = -v[n] * (1.0 / 9.0) - 0.5 * Da + 0.5 * ev[n] * ss[n];
             gdot[n] = clipc(g0, cl) * e0.y + gd[n];
-            logp[n] = -v[n] * v[n] / 18.0 - 0.5 * Da * v[n] - 0.5 * ev[n] * ss[n];
+            logp[n] = -v[n] * v[n] * (1.0 / 18.0) - 0.5 * Da * v[n] - 0.5 * ev[n] * ss[n];
         }
     } else if constexpr (MODEL == MODEL_ILL_NORMAL || MODEL == MODEL_NORMAL) {
         double acc[NV], gd[NV];
@@ -386,11 +386,11 @@ __device__ __forceinline__ void model_eval_nv(const ModelData &md, const double2
         }
 #pragma unroll
         for (int n = 0; n < NV; n++) {
-            double lp = -alpha[n] * alpha[n] / 50.0;
-            lp -= b0[n] * b0[n] / 50.0; lp -= b1[n] * b1[n] / 50.0; lp -= b2[n] * b2[n] / 50.0;
+            double lp = -alpha[n] * alpha[n] * (1.0 / 50.0);
+            lp -= b0[n] * b0[n] * (1.0 / 50.0); lp -= b1[n] * b1[n] * (1.0 / 50.0); lp -= b2[n] * b2[n] * (1.0 / 50.0);
             lp -= 0.5 * ell[n] * ell[n];
             lp += -0.5 * see[n] + lik[n];
-            double g0 = -alpha[n] / 25.0 + sr[n], g1 = -b0[n] / 25.0 + s1[n], g2 = -b1[n] / 25.0 + s2[n], g3 = -b2[n] / 25.0 + s3[n];
+            double g0 = -alpha[n] * (1.0 / 25.0) + sr[n], g1 = -b0[n] * (1.0 / 25.0) + s1[n], g2 = -b1[n] * (1.0 / 25.0) + s2[n], g3 = -b2[n] * (1.0 / 25.0) + s3[n];
             double g4 = -ell[n] + sigma[n] * sre[n];
             double g = gd[n];
             g += clipc(g0, cl) * ea.y; g += clipc(g1, cl) * eb0.y; g += clipc(g2, cl) * eb1.y; g += clipc(g3, cl) * eb2.y;

@@ -226,7 +226,7 @@ __device__ __forceinline__ KLScal kl_scalars(const KParams &p, double x1, double
 template <bool SUB>
 __device__ __forceinline__ void kl_node_terms(double w, double a, double sh, double ch, double lch, double logp, double gdot,
                                               const KLScal &k, double (&c)[5]) {
-    const double th = sh / ch;
+    const double th = sh * fast_rcp(ch);
     const double laj = k.e21 - lch;
     c[0] = w * (laj - logp);
     const double wg = w * gdot;
@@ -252,7 +252,7 @@ __device__ __forceinline__ void lane_kl_group(const KParams &p, const double2 *T
         const double ac = clipc(a, p.scale_clip);
         // one exp serves sinh and cosh: |abs error| <= 2^-53 * cosh, the same size as the rounding of the sums
         // these values enter (KL value/gradient stay within the 1e-12 parity bound, tests/test_gpu_parity.py)
-        const double E = exp(ac), Ei = 1.0 / E;
+        const double E = exp(ac), Ei = fast_rcp(E);
         sh[n] = 0.5 * (E - Ei);
         ch[n] = 0.5 * (E + Ei);
         lch[n] = log_cosh_from_exp(fabs(ac), fmin(E, Ei));
