@@ -74,64 +74,55 @@ __device__ __forceinline__ void opt_request(Opt &o, double a) {
 // costs a wavefront of occupancy (its by-reference state then round-trips through scratch memory, 8 doubles per call).
 __device__ __forceinline__ void dcstep(double &stx, double &fx, double &dx, double &sty, double &fy, double &dy, double &stp,
                                        double fp, double dp, bool &brackt, double stpmin, double stpmax) {
+    // The four cases of MINPACK's dcstep evaluate the same cubic-step expressions on different operands.  Lanes of
+    // one wavefront sit in different cases, so the expressions are written ONCE on case-selected operands: every lane
+    // performs exactly the operations (and roundings) of its own case, but the wavefront executes one copy of the
+    // divisions and the square root instead of up to four.
     const double sgnd = npsign(dp) * npsign(dx);
-    double theta, s, gamma, p, q, r, stpc, stpq, stpf;
-    if (fp > fx) {
-        theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
-        s = pymax3(fabs(theta), fabs(dx), fabs(dp));
-        gamma = s * sqrt((theta / s) * (theta / s) - (dx / s) * (dp / s));
-        if (stp < stx) gamma *= -1;
-        p = (gamma - dx) + theta;
-        q = ((gamma - dx) + gamma) + dp;
-        r = p / q;
-        stpc = stx + r * (stp - stx);
+    const int cs = fp > fx ? 1 : (sgnd < 0.0 ? 2 : (fabs(dp) < fabs(dx) ? 3 : 4));
+    const bool c4 = cs == 4;
+    // theta = 3 (A - B) / (C - D) + E + dp ; s = max(|theta|, |E|, |dp|) ; gamma = s sqrt((theta/s)^2 - (E/s)(dp/s))
+    const double A = c4 ? fp : fx, B = c4 ? fy : fp, C = c4 ? sty : stp, Dd = c4 ? stp : stx, E = c4 ? dy : dx;
+    const double theta = 3.0 * (A - B) / (C - Dd) + E + dp;
+    const double s = pymax3(fabs(theta), fabs(E), fabs(dp));
+    const double rad = (theta / s) * (theta / s) - (E / s) * (dp / s);
+    double gamma = s * sqrt(cs == 3 ? pymax2(0, rad) : rad);
+    const bool flip = cs == 1 ? stp < stx : (c4 ? stp > sty : stp > stx);
+    if (flip) gamma = -gamma;
+    const double P1 = cs == 1 ? dx : dp;
+    const double p = (gamma - P1) + theta;
+    const double q = cs == 3 ? (gamma + (dx - dp)) + gamma : ((gamma - P1) + gamma) + (cs == 1 ? dp : (cs == 2 ? dx : dy));
+    const double r = p / q;
+    const double base = cs == 1 ? stx : stp, oth = cs == 1 ? stp : (c4 ? sty : stx);
+    const double cub = base + r * (oth - base);
+    double stpc, stpq, stpf;
+    if (cs == 1) {
+        stpc = cub;
         stpq = stx + ((dx / ((fx - fp) / (stp - stx) + dx)) / 2.0) * (stp - stx);
         if (fabs(stpc - stx) <= fabs(stpq - stx)) stpf = stpc; else stpf = stpc + (stpq - stpc) / 2.0;
         brackt = true;
-    } else if (sgnd < 0.0) {
-        theta = 3 * (fx - fp) / (stp - stx) + dx + dp;
-        s = pymax3(fabs(theta), fabs(dx), fabs(dp));
-        gamma = s * sqrt((theta / s) * (theta / s) - (dx / s) * (dp / s));
-        if (stp > stx) gamma *= -1;
-        p = (gamma - dp) + theta;
-        q = ((gamma - dp) + gamma) + dx;
-        r = p / q;
-        stpc = stp + r * (stx - stp);
+    } else if (cs == 2 || cs == 3) {
         stpq = stp + (dp / (dp - dx)) * (stx - stp);
-        if (fabs(stpc - stp) > fabs(stpq - stp)) stpf = stpc; else stpf = stpq;
-        brackt = true;
-    } else if (fabs(dp) < fabs(dx)) {
-        theta = 3 * (fx - fp) / (stp - stx) + dx + dp;
-        s = pymax3(fabs(theta), fabs(dx), fabs(dp));
-        gamma = s * sqrt(pymax2(0, (theta / s) * (theta / s) - (dx / s) * (dp / s)));
-        if (stp > stx) gamma = -gamma;
-        p = (gamma - dp) + theta;
-        q = (gamma + (dx - dp)) + gamma;
-        r = p / q;
-        if (r < 0 && gamma != 0) stpc = stp + r * (stx - stp);
-        else if (stp > stx) stpc = stpmax;
-        else stpc = stpmin;
-        stpq = stp + (dp / (dp - dx)) * (stx - stp);
-        if (brackt) {
-            if (fabs(stpc - stp) < fabs(stpq - stp)) stpf = stpc; else stpf = stpq;
-            if (stp > stx) stpf = pymin2(stp + 0.66 * (sty - stp), stpf);
-            else stpf = pymax2(stp + 0.66 * (sty - stp), stpf);
-        } else {
+        if (cs == 2) {
+            stpc = cub;
             if (fabs(stpc - stp) > fabs(stpq - stp)) stpf = stpc; else stpf = stpq;
-            stpf = npclip(stpf, stpmin, stpmax);
+            brackt = true;
+        } else {
+            if (r < 0 && gamma != 0) stpc = cub;
+            else if (stp > stx) stpc = stpmax;
+            else stpc = stpmin;
+            if (brackt) {
+                if (fabs(stpc - stp) < fabs(stpq - stp)) stpf = stpc; else stpf = stpq;
+                if (stp > stx) stpf = pymin2(stp + 0.66 * (sty - stp), stpf);
+                else stpf = pymax2(stp + 0.66 * (sty - stp), stpf);
+            } else {
+                if (fabs(stpc - stp) > fabs(stpq - stp)) stpf = stpc; else stpf = stpq;
+                stpf = npclip(stpf, stpmin, stpmax);
+            }
         }
     } else {
-        if (brackt) {
-            theta = 3.0 * (fp - fy) / (sty - stp) + dy + dp;
-            s = pymax3(fabs(theta), fabs(dy), fabs(dp));
-            gamma = s * sqrt((theta / s) * (theta / s) - (dy / s) * (dp / s));
-            if (stp > sty) gamma = -gamma;
-            p = (gamma - dp) + theta;
-            q = ((gamma - dp) + gamma) + dy;
-            r = p / q;
-            stpc = stp + r * (sty - stp);
-            stpf = stpc;
-        } else if (stp > stx) stpf = stpmax;
+        if (brackt) stpf = cub;
+        else if (stp > stx) stpf = stpmax;
         else stpf = stpmin;
     }
     // interval update (_dcsrch.py:713-726), written as value selects so that the by-reference state stays in registers
