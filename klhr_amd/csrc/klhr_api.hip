@@ -356,7 +356,10 @@ static int run_phases(klhr_sampler *s, int phases, int64_t n_iters, int record_d
 extern "C" int klhr_step(klhr_sampler *s, int64_t n_iters, int record_draws, int record_diag) {
     if (!s || n_iters < 0) return KLHR_ERR_ARG;
     if (n_iters == 0) return KLHR_OK;
-    return run_phases(s, PH_ALL, n_iters, record_draws, record_diag);
+    int phases = PH_ALL;
+    // profiling aid (tools/phase_insitu.py): run the iteration loop with some phases left out to time the others in situ
+    if (const char *dbg = getenv("KLHR_DEBUG_PHASES")) phases = atoi(dbg) & PH_ALL;
+    return run_phases(s, phases, n_iters, record_draws, record_diag);
 }
 
 extern "C" int klhr_last_step_timing(klhr_sampler *s, double *kernel_ms, int *n_launches) {
