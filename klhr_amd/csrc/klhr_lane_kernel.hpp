@@ -195,11 +195,11 @@ __device__ inline void lane_close_window(const KParams &p, long long c, long lon
 // KL(eta) value + gradient (klhr_sinh.py:163-176) as a sum over *node groups*.
 //
 // The 8 quadrature nodes are processed in groups of G in {4, 2, 1} register-resident accumulator chains
-// (model_eval_nv<MODEL, G>); a group returns the partial sums (KL, dKL/deta0..3) of its nodes, and partials are combined
+// (model_eval_nv<MODEL, G>; G = 2 is not instantiated at present); a group returns the partial sums (KL, dKL/deta0..3) of its nodes, and partials are combined
 // in one fixed binary tree over the node index, ((0+1)+(2+3))+((4+5)+(6+7)).  Because of that fixed tree — and because
 // every per-node quantity is computed by the same (unfused or explicitly fused) instruction sequence whatever G is —
 // the result does not depend on *who* evaluates a group: the chain's own lane (two groups of 4, the normal case), or
-// idle lanes of the wavefront on its behalf (node-shared evaluation in the fit loop below).
+// eight lanes of the wavefront, one node each, on its behalf (node-shared evaluation in the fit loop below).
 #ifndef KLHR_NVG
 #define KLHR_NVG 4
 #endif
@@ -415,16 +415,17 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
                 if constexpr (VARIANT == VAR_GAUSS) {
                     if (ev4) lane_eval_kl_gauss<MODEL>(p, TR, o.xt, f, g);
                 } else {
-                    // ---- KL evaluation, node-shared when at most half of the lanes need one.
+                    // ---- KL evaluation, node-shared in the tail of the fit.
                     // Chains finish their fits after different numbers of evaluations (mean ~20 passes, slowest of 64
-                    // ~30), so in the second half of a fit most lanes idle.  With n4 <= 64/F requesting chains
-                    // (F = 2, 4, 8) each request is served by F lanes: lane j evaluates the group of 8/F nodes
-                    // number j % F of the chain ranked j / F among the requesters, reading that chain's (theta, rho)
-                    // from its LDS region, and the owner adds the F partials in the fixed tree of lane_kl_group.
+                    // ~30; in 40 % of the passes at most 8 chains of the wavefront are still fitting).  With n4 <= 8
+                    // requesting chains each request is served by 8 lanes: lane j evaluates quadrature node j % 8 of
+                    // the chain ranked j / 8 among the requesters, reading that chain's (theta, rho) from its LDS
+                    // region, and the owner adds the 8 partials in the fixed tree of lane_kl_group.  (Serving 9..32
+                    // requesters with 4 or 2 lanes each was measured too: such passes are rare, no gain.)
                     constexpr bool SUB = VARIANT == VAR_SUB;
                     const unsigned long long m4 = __ballot(ev4);
                     const int n4 = __popcll(m4);
-                    if (n4 > 32) {
+                    if (n4 > 8) {
                         if (ev4) {
                             const KLScal k = kl_scalars<SUB>(p, o.xt[1], o.xt[2], o.xt[3]);
                             double acc5[5] = {0, 0, 0, 0, 0};
@@ -438,7 +439,6 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
                             f = acc5[0]; g[0] = acc5[1]; g[1] = acc5[2]; g[2] = acc5[3]; g[3] = acc5[4];
                         }
                     } else if (n4 > 0) {
-                        const int lg = n4 <= 8 ? 3 : (n4 <= 16 ? 2 : 1);
                         const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m4 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m4, 0u));
                         if (ev4) {
                             reinterpret_cast<int *>(shx + LANE_OWN)[rank] = lane;
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
                             for (int j = 0; j < 4; j++) shx[LANE_XT + lane * 4 + j] = o.xt[j];
                         }
                         KLHR_WAVE_SYNC();
-                        const int r = lane >> lg, sub = lane & ((1 << lg) - 1);
+                        const int r = lane >> 3, node = lane & 7;
                         if (r < n4) {
                             const int ow = reinterpret_cast<const int *>(shx + LANE_OWN)[r];
                             const double x0 = shx[LANE_XT + ow * 4], x1 = shx[LANE_XT + ow * 4 + 1], x2 = shx[LANE_XT + ow * 4 + 2],
@@ -454,23 +454,18 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
                             const KLScal k = kl_scalars<SUB>(p, x1, x2, x3);
                             const double2 *TRo = reinterpret_cast<const double2 *>(lds + (size_t)ow * p.S);
                             double part[5];
-                            if (lg == 3) lane_kl_group<MODEL, SUB, 1>(p, TRo, x0, k, shx + LANE_Q + sub, shx + LANE_Q + 8 + sub, part);
-                            else if (lg == 2) lane_kl_group<MODEL, SUB, 2>(p, TRo, x0, k, shx + LANE_Q + 2 * sub, shx + LANE_Q + 8 + 2 * sub, part);
-                            else lane_kl_group<MODEL, SUB, 4>(p, TRo, x0, k, shx + LANE_Q + 4 * sub, shx + LANE_Q + 8 + 4 * sub, part);
+                            lane_kl_group<MODEL, SUB, 1>(p, TRo, x0, k, shx + LANE_Q + node, shx + LANE_Q + 8 + node, part);
 #pragma unroll
                             for (int j = 0; j < 5; j++) shx[LANE_PART + lane * 5 + j] = part[j];
                         }
                         KLHR_WAVE_SYNC();
                         if (ev4) {
-                            const double *pp = shx + LANE_PART + (rank << lg) * 5;
+                            const double *pp = shx + LANE_PART + rank * 40;
                             double r5[5];
 #pragma unroll
-                            for (int j = 0; j < 5; j++) {
-                                if (lg == 1) r5[j] = __dadd_rn(pp[j], pp[5 + j]);
-                                else if (lg == 2) r5[j] = __dadd_rn(__dadd_rn(pp[j], pp[5 + j]), __dadd_rn(pp[10 + j], pp[15 + j]));
-                                else r5[j] = __dadd_rn(__dadd_rn(__dadd_rn(pp[j], pp[5 + j]), __dadd_rn(pp[10 + j], pp[15 + j])),
-                                                       __dadd_rn(__dadd_rn(pp[20 + j], pp[25 + j]), __dadd_rn(pp[30 + j], pp[35 + j])));
-                            }
+                            for (int j = 0; j < 5; j++)
+                                r5[j] = __dadd_rn(__dadd_rn(__dadd_rn(pp[j], pp[5 + j]), __dadd_rn(pp[10 + j], pp[15 + j])),
+                                                  __dadd_rn(__dadd_rn(pp[20 + j], pp[25 + j]), __dadd_rn(pp[30 + j], pp[35 + j])));
                             f = r5[0]; g[0] = r5[1]; g[1] = r5[2]; g[2] = r5[3]; g[3] = r5[4];
                         }
                     }
