@@ -269,8 +269,26 @@ __device__ __forceinline__ void eval_objective(const KParams &p, const double2 *
 // ---- bit-exact (unfused, sequential) pieces: must round exactly like the NumPy expressions they restate
 #pragma clang fp contract(off)
 
+// Lane-strided rows of the chain state: lane l8 of the octet owns elements l8, l8+8, ...  A row is fetched from HBM
+// OCT_CH elements at a time with all loads of the chunk in flight at once (a wavefront of this kernel is alone on its
+// SIMD most of the time: nothing else hides a load's latency).
+constexpr int OCT_CH = 13;         // 13 * 8 = 104 coordinates per chunk
+
+template <class T>
+__device__ __forceinline__ void oct_load_chunk(const T *src, int stride, int l8, int k0, int D, T (&r)[OCT_CH]) {
+#pragma unroll
+    for (int k = 0; k < OCT_CH; k++) {
+        int i = l8 + 8 * (k0 + k);
+        i = i < D ? i : D - 1;
+        r[k] = src[(long long)i * stride];
+    }
+}
+
 // klhr_sinh.py:203-213 + Generator.multivariate_normal(method='svd') rank rule.  Z must hold the D standard
 // normals in stream order.  Writes rho into TR[i].y.
+// Two phases: the element-wise part r_i = m_i + sqrt(cov_i) z_rank(i) is lane-strided (each lane 1/8 of the
+// coordinates, row loads batched); only the norm, whose summation order NumPy fixes, is accumulated over all D by every
+// lane — from LDS.
 __device__ inline void direction_from_normals(const KParams &p, long long c, double2 *TR, const double *Z, int l8, double u_choice) {
     const int D = p.D, nc = p.ncol;
     const double *ev = p.eigvals + c * nc;
@@ -294,21 +312,35 @@ __device__ inline void direction_from_normals(const KParams &p, long long c, dou
         for (int j = 0; j < 4; j++) if (j < nc && cdf[j] / last <= u_choice) pick = j + 1;
         if (pick >= nc) pick = nc - 1;
     }
-    double nn = 0;
-    for (int i = 0; i < D; i++) {
-        double m = 0;
+    const int nk = (D + 7) >> 3;
+    for (int k0 = 0; k0 < nk; k0 += OCT_CH) {
+        double e0[OCT_CH], e1[OCT_CH], cv[OCT_CH];
+        int rk[OCT_CH];
+        oct_load_chunk(evec, nc, l8, k0, D, e0);
+        if (nc > 1) oct_load_chunk(evec + 1, nc, l8, k0, D, e1);
+        oct_load_chunk(cov, 1, l8, k0, D, cv);
+        oct_load_chunk(rank, 1, l8, k0, D, rk);
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (j < nc) {
-                double e = evec[i * nc + j];
-                if (pick >= 0) { if (j == pick) m = e; }
-                else m += (p.variant == VAR_GAUSS ? ev[j] : pj[j]) * e;      // klhr.py:150 weights by raw eigenvalues
+        for (int k = 0; k < OCT_CH; k++) {
+            const int i = l8 + 8 * (k0 + k);
+            if (i < D) {
+                double m = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (j < nc) {
+                        double e = j == 0 ? e0[k] : (j == 1 ? e1[k] : evec[i * nc + j]);
+                        if (pick >= 0) { if (j == pick) m = e; }
+                        else m += (p.variant == VAR_GAUSS ? ev[j] : pj[j]) * e;      // klhr.py:150 weights by raw eigenvalues
+                    }
+                }
+                TR[i].y = m + sqrt(cv[k]) * Z[rk[k]];
             }
         }
-        double r = m + sqrt(cov[i]) * Z[rank[i]];
-        nn += (r + p.tol) * (r + p.tol);
-        if ((i & 7) == l8) TR[i].y = r;
     }
+    KLHR_WAVE_SYNC();
+    double nn = 0;
+#pragma unroll 4
+    for (int i = 0; i < D; i++) { const double r = TR[i].y; nn += (r + p.tol) * (r + p.tol); }
     nn = sqrt(nn);
     KLHR_WAVE_SYNC();
     for (int i = l8; i < D; i += 8) TR[i].y = TR[i].y / nn;
@@ -318,14 +350,24 @@ __device__ inline void direction_from_normals(const KParams &p, long long c, dou
 // onlinemoments.py:10-18, lane-strided (element-wise: bit-exact)
 __device__ inline void om_update_strided(double *m, double *v, long long N, int D, int l8, const double2 *TR, const double *Z, bool fromZ, double clipb) {
     const double w = 1.0 / (double)N;
-    for (int i = l8; i < D; i += 8) {
-        double x = fromZ ? clipc(Z[i], clipb) : TR[i].x;
-        double mi = m[i], vi = v[i];
-        double d = x - mi;
-        mi += d * w;
-        vi += -vi * w + d * d * w * (1 - w);
-        m[i] = mi;
-        v[i] = vi;
+    const int nk = (D + 7) >> 3;
+    for (int k0 = 0; k0 < nk; k0 += OCT_CH) {
+        double mr[OCT_CH], vr[OCT_CH];
+        oct_load_chunk(m, 1, l8, k0, D, mr);
+        oct_load_chunk(v, 1, l8, k0, D, vr);
+#pragma unroll
+        for (int k = 0; k < OCT_CH; k++) {
+            const int i = l8 + 8 * (k0 + k);
+            if (i < D) {
+                double x = fromZ ? clipc(Z[i], clipb) : TR[i].x;
+                double mi = mr[k], vi = vr[k];
+                double d = x - mi;
+                mi += d * w;
+                vi += -vi * w + d * d * w * (1 - w);
+                m[i] = mi;
+                v[i] = vi;
+            }
+        }
     }
 }
 
@@ -339,19 +381,28 @@ __device__ inline void pca_update(const KParams &p, long long c, long long n_new
             for (int i = l8; i < D; i += 8) V[i * K + col] = Z[i];
         } else {
             const double w = ((double)(n_new - 1) - p.l) / (double)n_new;
-            for (int i = l8; i < D; i += 8) TR[i].y = V[i * K + col];
+            {
+                const int nk = (D + 7) >> 3;
+                for (int k0 = 0; k0 < nk; k0 += OCT_CH) {
+                    double vc[OCT_CH];
+                    oct_load_chunk(V + col, K, l8, k0, D, vc);
+#pragma unroll
+                    for (int k = 0; k < OCT_CH; k++) { const int i = l8 + 8 * (k0 + k); if (i < D) TR[i].y = vc[k]; }
+                }
+            }
             KLHR_WAVE_SYNC();
+            // (the two order-exact sums of a pass share one walk over the LDS column: each keeps its own order)
             double s = 0, udv = 0;
-            for (int i = 0; i < D; i++) { double vi = TR[i].y; s += vi * vi; }
+#pragma unroll 4
+            for (int i = 0; i < D; i++) { double vi = TR[i].y; s += vi * vi; udv += Z[i] * vi; }
             double nv = sqrt(s);
-            for (int i = 0; i < D; i++) udv += Z[i] * TR[i].y;
             KLHR_WAVE_SYNC();
             for (int i = l8; i < D; i += 8) TR[i].y = w * TR[i].y + (1 - w) * Z[i] * udv / (nv + PCA_TOL);
             KLHR_WAVE_SYNC();
             s = 0; udv = 0;
-            for (int i = 0; i < D; i++) { double vi = TR[i].y; s += vi * vi; }
+#pragma unroll 4
+            for (int i = 0; i < D; i++) { double vi = TR[i].y; s += vi * vi; udv += Z[i] * vi; }
             nv = sqrt(s);
-            for (int i = 0; i < D; i++) udv += Z[i] * TR[i].y;
             KLHR_WAVE_SYNC();
             for (int i = l8; i < D; i += 8) {
                 double vi = TR[i].y;
@@ -644,8 +695,15 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
                     KLHR_WAVE_SYNC();
                 }
                 om_update_strided(p.om_m + c * (long long)D, p.om_v + c * (long long)D, omN, D, l8, TR, Z, false, 0.0);
-                const double *mean = p.mean + c * (long long)D;
-                for (int i = l8; i < D; i += 8) Z[i] = __dsub_rn(TR[i].x, mean[i]);
+                {
+                    const int nk = (D + 7) >> 3;
+                    for (int k0 = 0; k0 < nk; k0 += OCT_CH) {
+                        double mr[OCT_CH];
+                        oct_load_chunk(p.mean + c * (long long)D, 1, l8, k0, D, mr);
+#pragma unroll
+                        for (int k = 0; k < OCT_CH; k++) { const int i = l8 + 8 * (k0 + k); if (i < D) Z[i] = __dsub_rn(TR[i].x, mr[k]); }
+                    }
+                }
                 KLHR_WAVE_SYNC();
                 pcan += 1;
                 pca_update(p, c, pcan, TR, Z, l8);
