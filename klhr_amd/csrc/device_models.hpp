@@ -181,6 +181,76 @@ __device__ __forceinline__ void model_eval(const ModelData &md, XR xr, double cl
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// model_eval for a point theta + t*rho whose (theta_i, rho_i) pairs sit in LDS, without gradient sink (the octet kernel's
+// KL nodes).  Same arithmetic in the same order as model_eval; the difference is the LDS schedule: coordinates are read
+// in blocks of TR_BLK with the NEXT block's reads issued before the current block is consumed (two register buffers,
+// ping-pong), because a wavefront alone on its SIMD otherwise waits out every block's LDS latency.
+#ifndef KLHR_TR_BLK
+#define KLHR_TR_BLK 8
+#endif
+template <class BODY>
+__device__ __forceinline__ void tr_pipelined(const double2 *TR, int i_begin, int D, BODY body) {
+    constexpr int B = KLHR_TR_BLK;
+    double2 a[B], b[B];
+#pragma unroll
+    for (int k = 0; k < B; k++) a[k] = TR[i_begin + k < D ? i_begin + k : D - 1];
+    for (int i0 = i_begin; i0 < D; i0 += 2 * B) {
+        if (i0 + B < D) {
+#pragma unroll
+            for (int k = 0; k < B; k++) b[k] = TR[i0 + B + k < D ? i0 + B + k : D - 1];
+        }
+#pragma unroll
+        for (int k = 0; k < B; k++) if (i0 + k < D) body(i0 + k, a[k]);
+        if (i0 + 2 * B < D) {
+#pragma unroll
+            for (int k = 0; k < B; k++) a[k] = TR[i0 + 2 * B + k < D ? i0 + 2 * B + k : D - 1];
+        }
+        if (i0 + B < D) {
+#pragma unroll
+            for (int k = 0; k < B; k++) if (i0 + B + k < D) body(i0 + B + k, b[k]);
+        }
+    }
+}
+
+template <int MODEL>
+__device__ __forceinline__ void model_eval_tr(const ModelData &md, const double2 *TR, double t, double cl, double &logp, double &gdot) {
+    const int D = md.D;
+    if constexpr (MODEL == MODEL_FUNNEL) {
+        const double2 e0 = TR[0];
+        const double v = fma(t, e0.y, e0.x);
+        const double ev = exp(-v);
+        if (ev > 0.0 && ev < INFINITY) {
+            const double Da = (double)md.n;
+            double ss = 0.0, gd = 0.0;
+            tr_pipelined(TR, 1, D, [&](int, double2 e) {
+                const double xi = fma(t, e.y, e.x);
+                ss += xi * xi;
+                gd += fmin(fmax(-ev * xi, -cl), cl) * e.y;
+            });
+            if (ss != ss) gd = NAN;
+            const double g0 = -v * (1.0 / 9.0) - 0.5 * Da + 0.5 * ev * ss;
+            gdot = clipc(g0, cl) * e0.y + gd;
+            logp = -v * v * (1.0 / 18.0) - 0.5 * Da * v - 0.5 * ev * ss;
+            return;
+        }
+    } else if constexpr (MODEL == MODEL_ILL_NORMAL || MODEL == MODEL_NORMAL) {
+        double acc = 0.0, gd = 0.0;
+        tr_pipelined(TR, 0, D, [&](int i, double2 e) {
+            const double xi = fma(t, e.y, e.x);
+            double gi;
+            if constexpr (MODEL == MODEL_ILL_NORMAL) { const double is = md.aux[i]; const double z = xi * is; acc += z * z; gi = -z * is; }
+            else { acc += xi * xi; gi = -xi; }
+            gd += fmin(fmax(gi, -cl), cl) * e.y;
+        });
+        if (acc != acc) gd = NAN;
+        gdot = gd;
+        logp = -0.5 * acc;
+        return;
+    }
+    model_eval<MODEL>(md, [&](int i, double &xi, double &ri) { double2 v = TR[i]; ri = v.y; xi = fma(t, v.y, v.x); }, cl, NoSink(), logp, gdot);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Octet-cooperative evaluation of ONE point theta + t*rho: lane l8 of the chain's octet visits coordinates
 // i = l8, l8+8, ... and the partial sums are combined with the commutative butterfly `sum8` (all 8 lanes end with the
 // same bits).  Used by the octet kernel for the 1-D line objective and the MH step, where all 8 lanes would otherwise

@@ -218,8 +218,7 @@ __device__ __forceinline__ void eval_objective(const KParams &p, const double2 *
         const double xn = p.xq[l8];
         const double t = s_ * xn + xt[0];
         double logp, gdot;
-        model_eval<MODEL>(p.md, [&](int i, double &xi, double &ri) { double2 v = TR[i]; ri = v.y; xi = fma(t, v.y, v.x); },
-                          INFINITY, NoSink(), logp, gdot);
+        model_eval_tr<MODEL>(p.md, TR, t, INFINITY, logp, gdot);
         const double wgr = w_l * gdot;
         const double s0 = grp_sum8(w_l * logp), s1 = grp_sum8(wgr), s2 = grp_sum8(wgr * xn * s_);
         f = -(s0 + xt[1]);
@@ -236,8 +235,7 @@ __device__ __forceinline__ void eval_objective(const KParams &p, const double2 *
         const double sh = 0.5 * (E - Ei), ch = 0.5 * (E + Ei);
         const double t = xt[0] + s_ * sh;
         double logp, gdot;
-        model_eval<MODEL>(p.md, [&](int i, double &xi, double &ri) { double2 v = TR[i]; ri = v.y; xi = fma(t, v.y, v.x); },
-                          SUB ? p.grad_clip : p.scale_clip, NoSink(), logp, gdot);
+        model_eval_tr<MODEL>(p.md, TR, t, SUB ? p.grad_clip : p.scale_clip, logp, gdot);
         const double w = w_l;
         const double th = sh * fast_rcp(ch);
         const double laj = (SUB ? -xt[1] : xt[2] - xt[1]) - log_cosh_from_exp(fabs(ac), fmin(E, Ei));
