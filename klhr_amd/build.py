@@ -12,7 +12,7 @@ OUT = os.path.join(HERE, "lib", "libklhr_hip.so")
 OBJ = os.path.join(HERE, "lib", "obj")
 DEPS = ["klhr_api.hip", "klhr_hot.hip", "klhr_kernels.hpp", "klhr_lane_kernel.hpp", "device_opt.hpp", "device_models.hpp",
         "device_rng.hpp", "zig_tables.h", os.path.join("..", "..", "include", "klhr.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"] + os.environ.get("KLHR_EXTRA_FLAGS", "").split()
 
 
 def needs_build():
