@@ -340,6 +340,9 @@ __device__ __forceinline__ double clip_acc(double x, double c, bool &sawnan) {
     return fmin(fmax(x, -c), c);
 }
 
+#ifndef KLHR_LDS_CHUNK
+#define KLHR_LDS_CHUNK 3
+#endif
 template <int MODEL, int NV>
 __device__ __forceinline__ void model_eval_nv(const ModelData &md, const double2 *TR, const double (&t)[NV], double cl,
                                               double (&logp)[NV], double (&gdot)[NV]) {
@@ -365,15 +368,16 @@ __device__ __forceinline__ void model_eval_nv(const ModelData &md, const double2
         // NaN exactly when xi is NaN, i.e. exactly when ss ends up NaN, so NaN-ness is restored after the loop; the
         // (rare) lanes with exp(-v) in {0, inf, NaN} take the careful loop below.  Either way the value equals
         // sum_i np.clip(g_i) rho_i accumulated in index order.
-        // coordinates are fetched from LDS three at a time (one wait per chunk instead of one per coordinate)
-        for (int i = 1; i < D; i += 3) {
-            const double2 ea = TR[i];
-            const double2 eb = TR[i + 1 < D ? i + 1 : i];
-            const double2 ec = TR[i + 2 < D ? i + 2 : i];
+        // coordinates are fetched from LDS KLHR_LDS_CHUNK at a time (one wait per chunk instead of one per coordinate)
+        constexpr int CH = KLHR_LDS_CHUNK;
+        for (int i = 1; i < D; i += CH) {
+            double2 ec[CH];
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
+            for (int k = 0; k < CH; k++) ec[k] = TR[i + k < D ? i + k : i];
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
                 if (i + k < D) {
-                    const double2 e = k == 0 ? ea : (k == 1 ? eb : ec);
+                    const double2 e = ec[k];
 #pragma unroll
                     for (int n = 0; n < NV; n++) {
                         double xi = fma(t[n], e.y, e.x);
