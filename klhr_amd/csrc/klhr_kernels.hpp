@@ -231,15 +231,15 @@ __device__ __forceinline__ double log_cosh_from_exp(double absa, double m) {
 #pragma clang fp contract(fast)
 
 template <int MODEL, int VARIANT>
-__device__ __forceinline__ void eval_objective(const KParams &p, const double2 *TR, int n, const double *xt, double asx_l,
-                                               double w_l, int l8, double &f, double *g) {
+__device__ __forceinline__ void eval_objective(const KParams &p, const ModelData &md, const double2 *TR, int n, const double *xt,
+                                               double asx_l, double w_l, int l8, double &f, double *g) {
     if (VARIANT == VAR_GAUSS && n != 1) {
         // klhr.py:109-124: y_n = s x_n + m, raw gradient, KL = -(sum_n w_n logp_n + eta1)
         const double s_ = exp(clipc(xt[1], p.scale_clip));
         const double xn = p.xq[l8];
         const double t = s_ * xn + xt[0];
         double logp, gdot;
-        model_eval_tr<MODEL>(p.md, TR, t, INFINITY, logp, gdot);
+        model_eval_tr<MODEL>(md, TR, t, INFINITY, logp, gdot);
         const double wgr = w_l * gdot;
         const double s0 = grp_sum8(w_l * logp), s1 = grp_sum8(wgr), s2 = grp_sum8(wgr * xn * s_);
         f = -(s0 + xt[1]);
@@ -256,7 +256,7 @@ __device__ __forceinline__ void eval_objective(const KParams &p, const double2 *
         const double sh = 0.5 * (E - Ei), ch = 0.5 * (E + Ei);
         const double t = xt[0] + s_ * sh;
         double logp, gdot;
-        model_eval_tr<MODEL>(p.md, TR, t, SUB ? p.grad_clip : p.scale_clip, logp, gdot);
+        model_eval_tr<MODEL>(md, TR, t, SUB ? p.grad_clip : p.scale_clip, logp, gdot);
         const double w = w_l;
         const double th = sh * fast_rcp(ch);
         const double laj = (SUB ? -xt[1] : xt[2] - xt[1]) - log_cosh_from_exp(fabs(ac), fmin(E, Ei));
@@ -273,7 +273,7 @@ __device__ __forceinline__ void eval_objective(const KParams &p, const double2 *
         g[3] = grp_sum8(c4);
     } else {
         double logp, gdot;
-        model_eval_split<MODEL>(p.md, TR, xt[0], INFINITY, l8, [](double v) { return grp_sum8(v); }, logp, gdot);
+        model_eval_split<MODEL>(md, TR, xt[0], INFINITY, l8, [](double v) { return grp_sum8(v); }, logp, gdot);
         f = -logp;
         g[0] = -gdot;
         g[1] = g[2] = g[3] = 0.0;
@@ -505,8 +505,21 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
     extern __shared__ double lds[];
     const int lane = threadIdx.x & 63, grp = lane >> 3, l8 = lane & 7;
     const long long c = (long long)blockIdx.x * 8 + grp;
-    if (c >= p.C) return;
     const int D = p.D;
+    // model data (ill-normal: 1/s_i table, glmm-poisson: covariates and counts) is staged in LDS behind the chain rows:
+    // the log-density loops then read it next to (theta_i, rho_i) instead of going to the vector cache per element
+    // (all 64 lanes copy, also those of octets beyond the last chain, which leave right after)
+    ModelData md = p.md;
+    {
+        const int naux = MODEL == MODEL_GLMM_POISSON ? 4 * p.md.n : (MODEL == MODEL_ILL_NORMAL ? D : 0);
+        if (naux > 0) {
+            double *aux_l = lds + (size_t)8 * p.S;
+            for (int i = lane; i < naux; i += 64) aux_l[i] = p.md.aux[i];
+            md.aux = aux_l;
+            KLHR_WAVE_SYNC();
+        }
+    }
+    if (c >= p.C) return;
     double2 *TR = reinterpret_cast<double2 *>(lds + (size_t)grp * p.S);
     double *Z = lds + (size_t)grp * p.S + 2 * (size_t)D;
 
@@ -575,7 +588,7 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
                     if (opt_cache_hit(o)) {
                         f = o.lf; g[0] = o.lg[0]; g[1] = o.lg[1]; g[2] = o.lg[2]; g[3] = o.lg[3];
                     } else {
-                        eval_objective<MODEL, VARIANT>(p, TR, o.n, o.xt, asx_l, w_l, l8, f, g);
+                        eval_objective<MODEL, VARIANT>(p, md, TR, o.n, o.xt, asx_l, w_l, l8, f, g);
                         opt_cache_store(o, f, g);
                         dg_pass++;
                     }
@@ -634,7 +647,7 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
         // =============================================================== KL / line probes (API + tests)
         if (p.phases & (PH_KL | PH_LINE)) {
             double f, g[4];
-            eval_objective<MODEL, VARIANT>(p, TR, (p.phases & PH_KL) ? (VARIANT == VAR_GAUSS ? 2 : (VARIANT == VAR_SUB ? 3 : 4)) : 1, eta, asx_l, w_l, l8, f, g);
+            eval_objective<MODEL, VARIANT>(p, md, TR, (p.phases & PH_KL) ? (VARIANT == VAR_GAUSS ? 2 : (VARIANT == VAR_SUB ? 3 : 4)) : 1, eta, asx_l, w_l, l8, f, g);
             if (l8 == 0) {
                 double *dd = p.d_diag + c * KLHR_NDIAG;
                 dd[0] = f; dd[1] = g[0]; dd[2] = g[1]; dd[3] = g[2]; dd[4] = g[3];
@@ -652,7 +665,7 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
             else zp = sa_T(rng_std_normal(rng), eta, p.tol, p.scale_clip, VARIANT == VAR_SUB);
             double logp, gdot;
             const double t = (l8 == 0) ? zp : 0.0;
-            model_eval<MODEL>(p.md, [&](int i, double &xi, double &ri) { double2 v = TR[i]; ri = v.y; xi = fma(t, v.y, v.x); },
+            model_eval<MODEL>(md, [&](int i, double &xi, double &ri) { double2 v = TR[i]; ri = v.y; xi = fma(t, v.y, v.x); },
                               INFINITY, NoSink(), logp, gdot);
             const double lp_p = __shfl(logp, (grp << 3) + 0);
             const double lp_c = __shfl(logp, (grp << 3) + 1);
@@ -707,7 +720,7 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
                 if (p.flags & FLAG_SCALE_DIR_COV) {
                     // _logp_grad(theta): gradient clipped at +-scale_clip feeds the density moments
                     double lp_, gd_;
-                    model_eval<MODEL>(p.md, [&](int i, double &xi, double &ri) { double2 v = TR[i]; xi = v.x; ri = 0.0; }, INFINITY,
+                    model_eval<MODEL>(md, [&](int i, double &xi, double &ri) { double2 v = TR[i]; xi = v.x; ri = 0.0; }, INFINITY,
                                       [&](int i, double gi) { if ((i & 7) == l8) Z[i] = gi; }, lp_, gd_);
                     KLHR_WAVE_SYNC();
                     om_update_strided(p.omd_m + c * (long long)D, p.omd_v + c * (long long)D, omN, D, l8, TR, Z, true,

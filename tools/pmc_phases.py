@@ -5,6 +5,9 @@ import numpy as np
 from klhr_amd import _lib
 model=sys.argv[1] if len(sys.argv)>1 else "funnel"; D=int(sys.argv[2]) if len(sys.argv)>2 else 10; C=int(sys.argv[3]) if len(sys.argv)>3 else 65536
 data=np.array([D-1.0]) if model=="funnel" else np.array([float(D)])
+if model=="glmm-poisson":
+    import json
+    d=json.load(open(os.path.join(ROOT,"klhr_amd","stan","glmm-poisson.json"))); data=np.concatenate([[float(d["n"])],d["year"],d["C"]])
 s=_lib.Sampler(_lib.MODEL_IDS[model],data,C,warmup=100)
 s.seed(np.arange(C,dtype=np.uint64))
 s.step(50); s.step(50); s.step(20)          # dispatches 1-3 (iter kernels)
