@@ -188,24 +188,35 @@ __device__ __forceinline__ void model_eval(const ModelData &md, XR xr, double cl
 #ifndef KLHR_TR_BLK
 #define KLHR_TR_BLK 8
 #endif
+template <int B>
+__device__ __forceinline__ void tr_load_block(const double2 *TR, int i0, int D, double2 (&r)[B]) {
+    if (i0 + B <= D) {          // whole block inside the row: immediate offsets, no index arithmetic
+#pragma unroll
+        for (int k = 0; k < B; k++) r[k] = TR[i0 + k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < B; k++) r[k] = TR[i0 + k < D ? i0 + k : D - 1];
+    }
+}
 template <class BODY>
 __device__ __forceinline__ void tr_pipelined(const double2 *TR, int i_begin, int D, BODY body) {
     constexpr int B = KLHR_TR_BLK;
     double2 a[B], b[B];
-#pragma unroll
-    for (int k = 0; k < B; k++) a[k] = TR[i_begin + k < D ? i_begin + k : D - 1];
+    tr_load_block<B>(TR, i_begin, D, a);
     for (int i0 = i_begin; i0 < D; i0 += 2 * B) {
-        if (i0 + B < D) {
+        if (i0 + B < D) tr_load_block<B>(TR, i0 + B, D, b);
+        if (i0 + B <= D) {
 #pragma unroll
-            for (int k = 0; k < B; k++) b[k] = TR[i0 + B + k < D ? i0 + B + k : D - 1];
+            for (int k = 0; k < B; k++) body(i0 + k, a[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < B; k++) if (i0 + k < D) body(i0 + k, a[k]);
         }
+        if (i0 + 2 * B < D) tr_load_block<B>(TR, i0 + 2 * B, D, a);
+        if (i0 + 2 * B <= D) {
 #pragma unroll
-        for (int k = 0; k < B; k++) if (i0 + k < D) body(i0 + k, a[k]);
-        if (i0 + 2 * B < D) {
-#pragma unroll
-            for (int k = 0; k < B; k++) a[k] = TR[i0 + 2 * B + k < D ? i0 + 2 * B + k : D - 1];
-        }
-        if (i0 + B < D) {
+            for (int k = 0; k < B; k++) body(i0 + B + k, b[k]);
+        } else if (i0 + B < D) {
 #pragma unroll
             for (int k = 0; k < B; k++) if (i0 + B + k < D) body(i0 + B + k, b[k]);
         }
