@@ -85,6 +85,8 @@ class ShardedKLHRSINH:
         1 + D + D^2 doubles per window closure, eigen-decomposition on every rank)."""
         from .klhr_sinh import KLHRSINH
         self.rank, self.world, self.local_rank = dist_env()
+        from . import _lib
+        self.local_rank = self.local_rank % max(1, _lib.device_count())      # more ranks than GPUs (rehearsals): share devices
         self.dist = dist
         self.pooled = pooled
         lo, hi = shard_range(chains_total, self.rank, self.world)

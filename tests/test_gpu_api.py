@@ -274,3 +274,65 @@ def test_ar1_and_earnings_targets_and_harnesses(tmp_path):
     assert r.exit_code == 0 and "RMSE(mean)" in r.output, r.output
     r = CliRunner().invoke(relax_main, ["-M", "200", "-w", "100", "--seed", "2", "--outdir", str(tmp_path), "-v", "klhr"])
     assert r.exit_code == 0 and "Number gradients" in r.output, r.output
+
+
+TWO_RANK_WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.environ["KLHR_ROOT"])
+import torch.distributed as dist
+from klhr_amd import BSModel
+from klhr_amd.parallel import ShardedKLHRSINH, dist_env
+rank, world, _ = dist_env()
+dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+stan = os.path.join(os.environ["KLHR_ROOT"], "klhr_amd", "stan")
+m = BSModel(os.path.join(stan, "funnel.stan"), os.path.join(stan, "funnel.json"))
+out = {}
+for mode in (False, "diag", "full"):
+    sh = ShardedKLHRSINH(m, 96, seed=5, pooled=mode, dist=dist, warmup=100)
+    sh.advance(50)                                   # up to and including the first window closure
+    s = sh.local._sampler
+    first = {"mean50": s.get("mean").tolist(), "cov50": s.get("cov").tolist()}
+    dr = sh.advance(70, record=True)
+    out[str(mode)] = {**first, "lo": sh.lo, "hi": sh.hi, "theta": s.get("theta").tolist(), "mean": s.get("mean").tolist(),
+                      "cov": s.get("cov").tolist(), "eigvecs": s.get("eigvecs").tolist(), "draws_shape": list(dr.shape)}
+dist.barrier()
+with open(os.path.join(os.environ["KLHR_OUT"], f"gpu_result_{rank}.json"), "w") as f:
+    json.dump(out, f)
+dist.destroy_process_group()
+'''
+
+
+def test_two_ranks_on_the_device_match_one_rank(tmp_path):
+    """The multi-GPU layout end to end (two processes, here sharing the one GPU; gloo for the collective): parity mode
+    reproduces the single-rank chains bit for bit; the pooled modes install the same pooled mean / covariance / directions
+    on every chain of every rank, equal to the single-rank pooled values up to the order of the cross-rank sum."""
+    import json, subprocess, sys
+    from klhr_amd.parallel import ShardedKLHRSINH
+    script = tmp_path / "worker.py"
+    script.write_text(TWO_RANK_WORKER)
+    env = dict(os.environ, KLHR_ROOT=ROOT, KLHR_OUT=str(tmp_path), MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29741", str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = [json.load(open(tmp_path / f"gpu_result_{r}.json")) for r in range(2)]
+    for mode in (False, "diag", "full"):
+        one = ShardedKLHRSINH(funnel_model(), 96, seed=5, pooled=mode, warmup=100)
+        one.advance(50)
+        s1 = one.local._sampler
+        mean50, cov50 = s1.get("mean").copy(), s1.get("cov").copy()
+        one.advance(70)
+        both = {k: np.concatenate([np.asarray(res[r][str(mode)][k]) for r in range(2)]) for k in ("theta", "mean", "cov", "eigvecs", "mean50", "cov50")}
+        assert (res[0][str(mode)]["lo"], res[0][str(mode)]["hi"], res[1][str(mode)]["lo"], res[1][str(mode)]["hi"]) == (0, 48, 48, 96)
+        assert res[0][str(mode)]["draws_shape"] == [70, 48, 10]
+        if mode is False:
+            for k in ("theta", "mean", "cov", "eigvecs"):
+                assert np.array_equal(both[k], s1.get(k)), k
+        else:
+            assert np.all(both["mean"] == both["mean"][0]) and np.all(both["cov"] == both["cov"][0])
+            # pooled over 96 chains by two partial sums vs one sum: equal to rounding at the first closure (afterwards
+            # the chains evolve from pooled values that differ in the last bits, so later states are not compared)
+            assert np.allclose(both["mean50"], mean50, rtol=1e-11, atol=1e-13)
+            assert np.allclose(both["cov50"], cov50, rtol=1e-9, atol=1e-13)
+            assert np.isfinite(both["theta"]).all()
