@@ -71,6 +71,14 @@ def lib():
         L.klhr_oracle_rng_raw.argtypes = [u64p, C.c_long, u64p]
         L.klhr_oracle_rng_double.argtypes = [u64p, C.c_long, dp]
         L.klhr_oracle_rng_normal.argtypes = [u64p, C.c_long, dp]
+        L.klhr_oracle_set_slice.argtypes = [vp, C.c_double, C.c_double, C.c_double, C.c_long]
+        L.klhr_oracle_slice_evals.argtypes = [vp]
+        L.klhr_oracle_slice_evals.restype = C.c_long
+        L.klhr_oracle_slice_status.argtypes = [vp]
+        L.klhr_oracle_uni_slice.argtypes = [vp, dp]
+        L.klhr_oracle_rng_exponential.argtypes = [u64p, C.c_long, dp]
+        L.klhr_oracle_rng_uniform_range.argtypes = [u64p, C.c_double, C.c_double]
+        L.klhr_oracle_rng_uniform_range.restype = C.c_double
         L.klhr_oracle_rng_uniform.argtypes = [u64p]
         L.klhr_oracle_rng_uniform.restype = C.c_double
         L.klhr_oracle_om_stream.argtypes = [C.c_int, C.c_long, dp, dp, dp, dp]
@@ -196,6 +204,15 @@ class Chain:
         self._L.klhr_oracle_random_direction(self._h, _dp(rho))
         return rho
 
+    def uni_slice(self, rho):
+        """slice.py:86-141 from the current theta along rho (increments the draw counter)."""
+        rho = np.ascontiguousarray(rho, dtype=np.float64)
+        self._L.klhr_oracle_uni_slice(self._h, _dp(rho))
+        return self.get("theta")
+
+    def slice_evals(self):
+        return int(self._L.klhr_oracle_slice_evals(self._h))
+
     def fit(self, rho):
         rho = np.ascontiguousarray(rho, dtype=np.float64)
         eta = np.zeros(4)
@@ -261,6 +278,18 @@ def KLHRChain(stem, data, seed=None, **kw):
     return Chain(stem, data, seed=seed, **d)
 
 
+def SliceChain(stem, data, seed=None, w=1.0, lower=-np.inf, upper=np.inf, maxiter=100000, **kw):
+    """A chain of the slice sampler with slice.py's constructor defaults (slice.py:14-32); m = inf only."""
+    d = dict(tol=1e-12, eigen_method_one=True, overrelaxed=False)
+    d.update(kw)
+    c = Chain(stem, data, seed=None, **d)
+    c._L.klhr_oracle_set_slice(c._h, float(w), float(lower), float(upper), int(maxiter))
+    c.variant = "slice"
+    if seed is not None:
+        c.init_tries = c._L.klhr_oracle_seed(c._h, int(seed), None)
+    return c
+
+
 def draw_batch(chains, niters):
     """Advance many chains niters draws each, OpenMP threads over chains (OMP_NUM_THREADS)."""
     arr = (C.c_void_p * len(chains))(*[c._h for c in chains])
@@ -279,6 +308,19 @@ def rng_raw(state4, n):
     out = np.zeros(n, dtype=np.uint64)
     lib().klhr_oracle_rng_raw(_u64p(st), n, _u64p(out))
     return out, st
+
+
+def rng_exponential(state4, n):
+    st = np.array(state4, dtype=np.uint64)
+    out = np.zeros(n)
+    lib().klhr_oracle_rng_exponential(_u64p(st), n, _dp(out))
+    return out, st
+
+
+def rng_uniform_range(state4, low, high):
+    st = np.array(state4, dtype=np.uint64)
+    v = lib().klhr_oracle_rng_uniform_range(_u64p(st), float(low), float(high))
+    return v, st
 
 
 def rng_double(state4, n):

@@ -35,6 +35,7 @@ sys.path.insert(0, ROOT)
 import klhr_sinh as ref_klhr_sinh          # noqa: E402  (reference)
 import klhr as ref_klhr                    # noqa: E402  (reference, Gaussian-proposal sibling)
 import sub_klhr_sinh as ref_sub            # noqa: E402  (reference, 3-parameter sibling)
+import slice as ref_slice                  # noqa: E402  (reference, slice sampler along the KLHR directions)
 import mh as ref_mh                        # noqa: E402
 import onlinemoments as ref_om             # noqa: E402
 import onlinepca as ref_pca                # noqa: E402
@@ -476,6 +477,63 @@ def g12_sub():
              s0_grad_evals=np.array([algo.grad_evals]))
 
 
+def g13_slice():
+    """Per-draw trace of the reference's Slice sampler (slice.py:160-183) through its own, untouched draw(); the
+    direction and the number of log-density evaluations are observed by wrapping methods, not by changing them."""
+    for name, seed, M, warmup, flags in [("funnel10", 0, 400, 100, {}), ("funnel10", 1, 300, 100, {"eigen_method_one": False}),
+                                         ("normal2", 0, 300, 100, {}), ("illnormal100", 0, 130, 100, {}),
+                                         ("funnel10", 2, 200, 100, {"scale_dir_cov": True})]:
+        tag = ("" if flags.get("eigen_method_one", True) else "_m2") + ("_s" if flags.get("scale_dir_cov") else "")
+        fn = os.path.join(HERE, f"g13_slice_{name}_s{seed}_w{warmup}{tag}.npz")
+        print("tracing", fn, flush=True)
+        model = make_model(name)
+        algo = ref_slice.Slice(model, seed=seed, warmup=warmup, **flags)
+        calls = [0]
+        real_ld = model.log_density
+
+        def counting_ld(x, *a, _f=real_ld, **k):
+            calls[0] += 1
+            return _f(x, *a, **k)
+
+        model.log_density = counting_ld
+        rhos = []
+        real_dir = algo._random_direction
+
+        def rec_dir(_f=real_dir):
+            r = _f()
+            rhos.append(np.array(r, dtype=np.float64).copy())
+            return r
+
+        algo._random_direction = rec_dir
+        rec = {k: [] for k in ["state_before", "theta_before", "rho", "theta_after", "state_after", "evals", "accprob"]}
+        snaps = {}
+        theta0 = algo.theta.copy()
+        state_init = st4(algo.rng)
+        for m in range(1, M + 1):
+            rec["state_before"].append(st4(algo.rng))
+            rec["theta_before"].append(algo.theta.copy())
+            calls[0] = 0
+            th = algo.draw()
+            rec["rho"].append(rhos[-1])
+            rec["theta_after"].append(np.array(th, dtype=np.float64).copy())
+            rec["state_after"].append(st4(algo.rng))
+            rec["evals"].append(calls[0])
+            rec["accprob"].append(float(np.asarray(algo.acceptance_probability).reshape(-1)[0]))
+            if m in (49, 50, 51, 99, 100, 101, 120, M):
+                snaps[m] = dict(mean=np.array(algo._mean, dtype=np.float64).copy(), cov=np.array(algo._cov, dtype=np.float64).copy(),
+                                eigvecs=np.array(algo._eigvecs, dtype=np.float64).copy(), eigvals=np.array(algo._eigvals, dtype=np.float64).copy(),
+                                om_m=algo._onlinemoments.m.copy(), om_v=algo._onlinemoments.v.copy(),
+                                omd_m=algo._onlinemoments_density.m.copy(), omd_v=algo._onlinemoments_density.v.copy(),
+                                pca_v=algo._onlinepca.v.copy())
+        out = {k: np.array(v) for k, v in rec.items()}
+        out.update(theta0=theta0, state_init=state_init, M=np.array([M]), warmup=np.array([warmup]), seed=np.array([seed]),
+                   snap_draws=np.array(sorted(snaps)))
+        for m, d in snaps.items():
+            for k, v in d.items():
+                out[f"snap{m}_{k}"] = v
+        np.savez(fn, **out)
+
+
 def g11_klhr():
     for name, seed, M, warmup, flags in [("funnel10", 0, 400, 100, {}), ("funnel10", 1, 400, 100, {"eigen_method_one": False}),
                                          ("normal2", 0, 300, 100, {}), ("illnormal100", 0, 130, 100, {})]:
@@ -559,9 +617,9 @@ def g10_overrelaxed():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g7", "g8", "g8p", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g7", "g8", "g8p", "g9", "g10", "g11", "g12", "g13"]
     fns = {"g1": g1_quadrature, "g2": g2_rng, "g3": g3_primitives, "g4": g4_kl, "g7": g7_online,
-           "g8": g8_chains, "g8p": g8_untouched, "g9": g9_mh, "g10": g10_overrelaxed, "g11": g11_klhr, "g12": g12_sub}
+           "g8": g8_chains, "g8p": g8_untouched, "g9": g9_mh, "g10": g10_overrelaxed, "g11": g11_klhr, "g12": g12_sub, "g13": g13_slice}
     for w in which:
         print("==", w, flush=True)
         fns[w]()
