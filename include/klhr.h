@@ -69,7 +69,9 @@ typedef struct klhr_config {
                                                               * global RNG there: distribution-exact, not stream-exact) */
     int32_t variant;           /* 0: KLHRSINH, 4-parameter sinh-arcsinh proposal (klhr_sinh.py)
                                 * 1: KLHR, 2-parameter Gaussian proposal (klhr.py:15-223); eta is then (m, log s, 0, 0)
-                                * 2: SUBKLHRSINH, 3-parameter sinh-arcsinh, d == 1 (sub_klhr_sinh.py); eta = (m, log s, e, 0) */
+                                * 2: SUBKLHRSINH, 3-parameter sinh-arcsinh, d == 1 (sub_klhr_sinh.py); eta = (m, log s, e, 0)
+                                * 3: Slice, Neal's univariate slice sampler along the same direction draw (slice.py:12-183);
+                                *    no fit; K, N, grad_clip, scale_clip, overrelaxed are ignored; see klhr_set_slice */
     const double *quad_x;      /* N probabilists' Gauss-Hermite nodes   (klhr_sinh.py:44-47) */
     const double *quad_w;      /* N weights                                                  */
     const double *quad_asinh_x;/* N values asinh(x_n) (host-computed, np.arcsinh)            */
@@ -118,6 +120,14 @@ KLHR_API int klhr_random_direction(klhr_sampler *s, double *rho_out);
 KLHR_API int klhr_fit(klhr_sampler *s, const double *rho, double *eta_out);
 KLHR_API int klhr_metropolis(klhr_sampler *s, const double *eta, const double *rho);
 KLHR_API int klhr_adapt(klhr_sampler *s);
+
+/* Slice sampler (variant 3) — replaces Slice.__init__'s w / lower / upper (slice.py:19-22; m = inf only: the reference's
+ * finite-m branch refers to undefined names and cannot run) and Slice._uni_slice(rho) (slice.py:86-141, also _draw += 1).
+ * max_evals caps the log-density evaluations of one draw (the reference loops forever on a density that never
+ * compares); reaching it sets bit 4 of the chain's status.  klhr_step / klhr_random_direction / klhr_adapt serve
+ * draw() (slice.py:160-183) as for the other variants; grad_evals counts log-density evaluations.               */
+KLHR_API int klhr_set_slice(klhr_sampler *s, double w, double lower, double upper, int64_t max_evals);
+KLHR_API int klhr_slice_step(klhr_sampler *s, const double *rho);
 
 /* replaces: KLHRSINH.KL(eta, rho) (klhr_sinh.py:163-176) at each chain's current theta             */
 KLHR_API int klhr_kl_eval(klhr_sampler *s, const double *eta, const double *rho, double *value_out, double *grad_out);

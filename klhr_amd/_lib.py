@@ -64,6 +64,8 @@ def lib():
         "klhr_fit": (C.c_int, [vp, dp, dp]),
         "klhr_metropolis": (C.c_int, [vp, dp, dp]),
         "klhr_adapt": (C.c_int, [vp]),
+        "klhr_set_slice": (C.c_int, [vp, C.c_double, C.c_double, C.c_double, C.c_int64]),
+        "klhr_slice_step": (C.c_int, [vp, dp]),
         "klhr_kl_eval": (C.c_int, [vp, dp, dp, dp, dp]),
         "klhr_line_eval": (C.c_int, [vp, dp, dp, dp]),
         "klhr_log_density_gradient": (C.c_int, [vp, dp, C.c_int64, dp, dp]),
@@ -89,7 +91,7 @@ def lib():
 EXPORTS = ["klhr_create", "klhr_destroy", "klhr_last_error", "klhr_abi_version", "klhr_device_count", "klhr_dim", "klhr_chains", "klhr_sync",
            "klhr_kernel_variant",
            "klhr_seed", "klhr_seed_state", "klhr_window_closures", "klhr_step", "klhr_get_draws", "klhr_random_direction",
-           "klhr_fit", "klhr_metropolis", "klhr_adapt", "klhr_kl_eval", "klhr_line_eval", "klhr_log_density_gradient",
+           "klhr_fit", "klhr_metropolis", "klhr_adapt", "klhr_set_slice", "klhr_slice_step", "klhr_kl_eval", "klhr_line_eval", "klhr_log_density_gradient",
            "klhr_primitives", "klhr_get_state", "klhr_set_state", "klhr_mh_seed", "klhr_mh_step", "klhr_pool_stats",
            "klhr_pool_apply", "klhr_pool_gram", "klhr_pool_apply_full", "klhr_last_step_timing"]
 
@@ -216,6 +218,13 @@ class Sampler:
 
     def adapt(self):
         self._ck(self._L.klhr_adapt(self._h), "klhr_adapt")
+
+    def set_slice(self, w=1.0, lower=-np.inf, upper=np.inf, max_evals=100000):
+        self._ck(self._L.klhr_set_slice(self._h, float(w), float(lower), float(upper), int(max_evals)), "klhr_set_slice")
+
+    def slice_step(self, rho):
+        rho = np.ascontiguousarray(rho, dtype=np.float64).reshape(self.C, self.D)
+        self._ck(self._L.klhr_slice_step(self._h, dptr(rho)), "klhr_slice_step")
 
     def kl_eval(self, eta, rho):
         rho = np.ascontiguousarray(rho, dtype=np.float64).reshape(self.C, self.D)

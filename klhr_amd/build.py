@@ -1,7 +1,7 @@
 """Build libklhr_hip.so for gfx950 in-tree (klhr_amd/lib/).  `python -m klhr_amd.build [--force] [-v]`
 
-Seven translation units are compiled in parallel and linked: klhr_api.hip (C ABI + small kernels) and klhr_hot.hip six
-times, once per (sampler variant, over-relaxation) pair — see the comment at the top of klhr_hot.hip."""
+Eight translation units are compiled in parallel and linked: klhr_api.hip (C ABI + small kernels) and klhr_hot.hip once
+per (sampler variant, over-relaxation) pair (six) plus once for the slice sampler — see the comment at the top of klhr_hot.hip."""
 import os
 import subprocess
 import sys
@@ -32,6 +32,7 @@ def build(force=False, verbose=False, extra=()):
     for v in (0, 1, 2):
         for o in (0, 1):
             jobs.append((f"hot_v{v}_o{o}.o", ["-c", os.path.join(SRC, "klhr_hot.hip"), f"-DKLHR_VARIANT={v}", f"-DKLHR_OVERRELAX={o}"]))
+    jobs.append(("hot_v3_o0.o", ["-c", os.path.join(SRC, "klhr_hot.hip"), "-DKLHR_VARIANT=3", "-DKLHR_OVERRELAX=0"]))     # slice.py
     procs = []
     for name, args in jobs:
         cmd = [hipcc] + flags + args + ["-o", os.path.join(OBJ, name)]

@@ -64,4 +64,25 @@ __device__ inline double rng_std_normal(Pcg64 &g) {
 // Generator.uniform() == 0.0 + (1.0 - 0.0) * next_double
 __device__ __forceinline__ double rng_uniform(Pcg64 &g) { return pcg_next_double(g); }
 
+// Generator.uniform(low, high): low + (high - low) * next_double, unfused (slice.py:95,130)
+__device__ __forceinline__ double rng_uniform_range(Pcg64 &g, double low, double high) {
+    return __dadd_rn(low, __dmul_rn(high - low, pcg_next_double(g)));
+}
+
+// Generator.exponential(): NumPy's 256-layer ziggurat for the standard exponential (distributions.c:
+// random_standard_exponential / standard_exponential_unlikely), used by the reference's slice.py:93
+__device__ inline double rng_std_exponential(Pcg64 &g) {
+    const double ZIG_EXP_R = 7.69711747013104972;
+    for (;;) {
+        uint64_t ri = pcg_next64(g);
+        ri >>= 3;
+        const int idx = (int)(ri & 0xff);
+        ri >>= 8;
+        const double x = __dmul_rn((double)ri, KLHR_ZIG_WE[idx]);
+        if (ri < KLHR_ZIG_KE[idx]) return x;            // ~98.9 % of draws
+        if (idx == 0) return ZIG_EXP_R - log1p(-pcg_next_double(g));
+        if (__dadd_rn(__dmul_rn(KLHR_ZIG_FE[idx - 1] - KLHR_ZIG_FE[idx], pcg_next_double(g)), KLHR_ZIG_FE[idx]) < exp(-x)) return x;
+    }
+}
+
 }  // namespace klhr

@@ -21,6 +21,7 @@ void launch_hot_v1_o0(const KParams &, int, bool, hipStream_t);
 void launch_hot_v1_o1(const KParams &, int, bool, hipStream_t);
 void launch_hot_v2_o0(const KParams &, int, bool, hipStream_t);
 void launch_hot_v2_o1(const KParams &, int, bool, hipStream_t);
+void launch_hot_v3_o0(const KParams &, int, bool, hipStream_t);
 }  // namespace klhr
 
 using namespace klhr;
@@ -186,7 +187,7 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
     if (cfg->J < 1 || cfg->J > 3) return fail("klhr_create: need 1 <= J <= 3");
     if (cfg->overrelaxed && (cfg->K < 1 || cfg->K > 64)) return fail("klhr_create: overrelaxed needs 1 <= K <= 64");
     if (cfg->chains < 1) return fail("klhr_create: chains < 1");
-    if (cfg->variant < 0 || cfg->variant > 2) return fail("klhr_create: variant must be 0 (KLHRSINH), 1 (KLHR) or 2 (SUBKLHRSINH)");
+    if (cfg->variant < 0 || cfg->variant > 3) return fail("klhr_create: variant must be 0 (KLHRSINH), 1 (KLHR), 2 (SUBKLHRSINH) or 3 (Slice)");
     if (!model_data || n_model_data < 1 || !cfg->quad_x || !cfg->quad_w || !cfg->quad_asinh_x) return fail("klhr_create: null data");
     int D = 0, n = 0;
     std::vector<double> aux;
@@ -236,6 +237,8 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
     while (SL % 32 != 2) SL++;
     s->S_lane = SL;
     s->use_lane = (D <= 26) && (((size_t)64 * SL + 624) * 8 <= 64 * 1024);   // + LANE_LDS_EXTRA (klhr_lane_kernel.hpp)
+    if (cfg->variant == 3) s->use_lane = false;          // the slice sampler runs on the octet kernel only
+    else
     if (const char *kk = getenv("KLHR_KERNEL")) {
         if (!strcmp(kk, "octet")) s->use_lane = false;
         else if (!strcmp(kk, "lane") && ((size_t)64 * SL + 624) * 8 <= 64 * 1024) s->use_lane = true;
@@ -260,6 +263,7 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
     k.tol = cfg->tol; k.scale_clip = cfg->scale_clip; k.grad_clip = cfg->grad_clip; k.initscale = cfg->initscale; k.l = cfg->l;
     for (int i = 0; i < 8; i++) { k.xq[i] = cfg->quad_x[i]; k.wq[i] = cfg->quad_w[i]; k.asx[i] = cfg->quad_asinh_x[i]; }
     k.variant = cfg->variant;
+    k.sl_w = 1.0; k.sl_lower = -INFINITY; k.sl_upper = INFINITY; k.sl_maxiter = 100000;      // slice.py:19-22 defaults
     TRY(dalloc(s, &s->d_aux, aux.size()));
     if (!aux.empty()) TRY(hip_try(hipMemcpy(s->d_aux, aux.data(), aux.size() * 8, hipMemcpyHostToDevice), "hipMemcpy aux"));
     k.md.aux = s->d_aux; k.md.D = D; k.md.n = n;
@@ -312,7 +316,8 @@ static int launch_iter(klhr_sampler *s, const KParams &kp_in) {
     KParams kp = kp_in;
     kp.S = s->use_lane ? s->S_lane : s->S;
     const bool o = s->cfg.overrelaxed != 0;
-    if (s->cfg.variant == 2) (o ? launch_hot_v2_o1 : launch_hot_v2_o0)(kp, s->cfg.model_id, s->use_lane, s->stream);
+    if (s->cfg.variant == 3) launch_hot_v3_o0(kp, s->cfg.model_id, false, s->stream);
+    else if (s->cfg.variant == 2) (o ? launch_hot_v2_o1 : launch_hot_v2_o0)(kp, s->cfg.model_id, s->use_lane, s->stream);
     else if (s->cfg.variant == 1) (o ? launch_hot_v1_o1 : launch_hot_v1_o0)(kp, s->cfg.model_id, s->use_lane, s->stream);
     else (o ? launch_hot_v0_o1 : launch_hot_v0_o0)(kp, s->cfg.model_id, s->use_lane, s->stream);
     HIPCHECK(s, hipGetLastError());
@@ -462,6 +467,24 @@ extern "C" int klhr_metropolis(klhr_sampler *s, const double *eta, const double 
     int rc = h2d(s, s->kp.d_rho, rho, (size_t)s->C * s->D * 8);
     if (rc) return rc;
     rc = h2d(s, s->kp.d_eta, eta, (size_t)s->C * 4 * 8);
+    if (rc) return rc;
+    rc = run_phases(s, PH_MH, 1, 0, 1);
+    if (rc) return rc;
+    return klhr_sync(s);
+}
+
+extern "C" int klhr_set_slice(klhr_sampler *s, double w, double lower, double upper, int64_t max_evals) {
+    if (!s) return KLHR_ERR_ARG;
+    if (s->cfg.variant != 3) { s->err = "klhr_set_slice: handle was not created with variant 3 (Slice)"; return KLHR_ERR_STATE; }
+    if (!(w > 0) || !(lower < upper) || max_evals < 3 || max_evals > 2000000000) { s->err = "klhr_set_slice: need w > 0, lower < upper, 3 <= max_evals"; return KLHR_ERR_ARG; }
+    s->kp.sl_w = w; s->kp.sl_lower = lower; s->kp.sl_upper = upper; s->kp.sl_maxiter = (int)max_evals;
+    return KLHR_OK;
+}
+
+extern "C" int klhr_slice_step(klhr_sampler *s, const double *rho) {
+    if (!s || !rho) return KLHR_ERR_ARG;
+    if (s->cfg.variant != 3) { s->err = "klhr_slice_step: handle was not created with variant 3 (Slice)"; return KLHR_ERR_STATE; }
+    int rc = h2d(s, s->kp.d_rho, rho, (size_t)s->C * s->D * 8);
     if (rc) return rc;
     rc = run_phases(s, PH_MH, 1, 0, 1);
     if (rc) return rc;

@@ -7,7 +7,7 @@
 #include "klhr_lane_kernel.hpp"
 
 #ifndef KLHR_VARIANT
-#error "compile with -DKLHR_VARIANT=0|1|2 -DKLHR_OVERRELAX=0|1"
+#error "compile with -DKLHR_VARIANT=0|1|2|3 -DKLHR_OVERRELAX=0|1"
 #endif
 #define KLHR_CAT_(a, b, c, d) a##b##c##d
 #define KLHR_CAT(a, b, c, d) KLHR_CAT_(a, b, c, d)
@@ -17,7 +17,9 @@ namespace klhr {
 void KLHR_CAT(launch_hot_v, KLHR_VARIANT, _o, KLHR_OVERRELAX)(const KParams &kp, int model_id, bool lane, hipStream_t stream) {
     constexpr int V = KLHR_VARIANT;
     constexpr bool O = KLHR_OVERRELAX != 0;
-    if (lane) {
+    if constexpr (V == VAR_SLICE) { (void)lane; }        // slice.py runs on the octet kernel only (klhr_api.hip)
+    if (lane && V != VAR_SLICE) {
+      if constexpr (V != VAR_SLICE) {
         const dim3 grid((kp.C + 63) / 64), block(64);
         const size_t lds = ((size_t)64 * kp.S + LANE_LDS_EXTRA) * sizeof(double);
         switch (model_id) {
@@ -28,6 +30,7 @@ void KLHR_CAT(launch_hot_v, KLHR_VARIANT, _o, KLHR_OVERRELAX)(const KParams &kp,
         case KLHR_MODEL_EARNINGS: hipLaunchKernelGGL((klhr_lane_kernel<MODEL_EARNINGS, O, V>), grid, block, lds, stream, kp); break;
         default: hipLaunchKernelGGL((klhr_lane_kernel<MODEL_NORMAL, O, V>), grid, block, lds, stream, kp); break;
         }
+      }
     } else {
         const dim3 grid((kp.C + 7) / 8), block(64);
         // chain rows + staged model data (klhr_iter_kernel: ill-normal D doubles, glmm-poisson 4n doubles)

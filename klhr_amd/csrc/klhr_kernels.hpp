@@ -34,7 +34,7 @@
 namespace klhr {
 
 enum { PH_DIR = 1, PH_FIT = 2, PH_MH = 4, PH_ADAPT = 8, PH_ALL = 15, PH_KL = 16, PH_LINE = 32 };
-enum { VAR_SINH = 0, VAR_GAUSS = 1, VAR_SUB = 2 };   // klhr_sinh.py / klhr.py / sub_klhr_sinh.py
+enum { VAR_SINH = 0, VAR_GAUSS = 1, VAR_SUB = 2, VAR_SLICE = 3 };   // klhr_sinh.py / klhr.py / sub_klhr_sinh.py / slice.py
 // OnlinePCA's own tolerance: both samplers construct OnlinePCA(D, K=J, l=l) with its default tol = 1e-10
 // (klhr_sinh.py:62, klhr.py:63, onlinepca.py:5), independently of the sampler's `tol`.
 #define PCA_TOL 1e-10
@@ -44,6 +44,7 @@ struct KParams {
     int C, D, S, ncol, J, K, flags, phases, n_iters, variant;   // variant: 0 KLHRSINH (klhr_sinh.py), 1 KLHR (klhr.py)
     ModelData md;
     double tol, scale_clip, grad_clip, initscale, l;
+    double sl_w, sl_lower, sl_upper; int sl_maxiter;      // Slice (slice.py:19-22): width, bounds; evaluation cap per draw
     double xq[8], wq[8], asx[8];   // quadrature nodes, weights, asinh(node)
     double *theta;
     uint64_t *rng;
@@ -349,7 +350,7 @@ __device__ inline void direction_from_normals(const KParams &p, long long c, dou
                     if (j < nc) {
                         double e = j == 0 ? e0[k] : (j == 1 ? e1[k] : evec[i * nc + j]);
                         if (pick >= 0) { if (j == pick) m = e; }
-                        else m += (p.variant == VAR_GAUSS ? ev[j] : pj[j]) * e;      // klhr.py:150 weights by raw eigenvalues
+                        else m += ((p.variant == VAR_GAUSS || p.variant == VAR_SLICE) ? ev[j] : pj[j]) * e;      // klhr.py:150 weights by raw eigenvalues
                     }
                 }
                 TR[i].y = m + sqrt(cv[k]) * Z[rk[k]];
@@ -541,6 +542,7 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
     double eta[4] = {0, 0, 0, 0};
     double dg_x0 = 0, dg_mode = 0, dg_hinv1 = 0, dg_fun2 = 0, dg_init[4] = {0, 0, 0, 0}, dg_zp = 0, dg_r = 0, dg_logu = 0;
     int dg_nfev1 = 0, dg_nit1 = 0, dg_st1 = 0, dg_nfev2 = 0, dg_nit2 = 0, dg_st2 = 0, dg_acc = 0, dg_fb = 0, dg_pass = 0;
+    bool sl_capped = false;
 
 #ifdef KLHR_STAMPS
     unsigned long long stamp_t = __builtin_readcyclecounter(), st_dir = 0, st_eval = 0, st_adv = 0, st_mh = 0, st_adapt = 0, st_out = 0, st_idle = 0;
@@ -569,6 +571,7 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
 
         KLHR_STAMP(st_dir);
         // =============================================================== fit (klhr_sinh.py:182-201)
+        if constexpr (VARIANT != VAR_SLICE) {
         if (p.phases & PH_FIT) {
             Opt o;
             {
@@ -643,9 +646,10 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
         } else {
             for (int k = 0; k < 4; k++) eta[k] = p.d_eta[c * 4 + k];
         }
+        }
 
         // =============================================================== KL / line probes (API + tests)
-        if (p.phases & (PH_KL | PH_LINE)) {
+        if (VARIANT != VAR_SLICE && (p.phases & (PH_KL | PH_LINE))) {
             double f, g[4];
             eval_objective<MODEL, VARIANT>(p, md, TR, (p.phases & PH_KL) ? (VARIANT == VAR_GAUSS ? 2 : (VARIANT == VAR_SUB ? 3 : 4)) : 1, eta, asx_l, w_l, l8, f, g);
             if (l8 == 0) {
@@ -655,6 +659,61 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
         }
 
         KLHR_STAMP(st_idle);
+        // =============================================================== slice step (slice.py:86-141) instead of fit + MH
+        // Neal's univariate slice sampler along rho: log y = g(0) - Exp(1); bracket (L, R) of width w placed uniformly
+        // around 0 and stepped out while g > log y (m = inf); then shrinkage towards 0 until a point inside the slice is
+        // drawn.  One evaluation site serves the three loops: the chains of a wavefront sit in different loops and the
+        // log density g(x) = logp(theta + x rho) is the octet-cooperative evaluation of the line objective.
+        if constexpr (VARIANT == VAR_SLICE) {
+            if (p.phases & PH_MH) {
+                draw += 1;
+                int st = 0, evals = 0;             // 0: g(0), 1: stepping L out, 2: stepping R out, 3: shrinking, 4: done
+                double x = 0.0, logy = 0.0, L = 0.0, R = 0.0, x1 = 0.0;
+                const double w = p.sl_w;
+                for (;;) {
+                    if (st != 4) {
+                        double lp, gd;
+                        model_eval_split<MODEL>(md, TR, x, INFINITY, l8, [](double v) { return grp_sum8(v); }, lp, gd);
+                        evals++;
+                        const bool capped = evals > p.sl_maxiter;
+                        if (st == 0) {
+                            logy = lp - rng_std_exponential(rng);
+                            const double u = rng_uniform_range(rng, 0.0, w);
+                            L = 0.0 - u; R = 0.0 + (w - u);
+                            st = 1;
+                        } else if (st == 1) {
+                            if (lp <= logy || capped) st = 2; else L -= w;
+                        } else if (st == 2) {
+                            if (lp <= logy || capped) st = 3; else R += w;
+                        } else {
+                            if (lp >= logy || capped) st = 4;
+                            else if (x1 > 0.0) R = x1; else L = x1;
+                        }
+                        if (capped) { dg_st2 = 1; sl_capped = true; }
+                        // next request (the bound checks of slice.py:102,108 come before the evaluation)
+                        if (st == 1) { if (L <= p.sl_lower) st = 2; else x = L; }
+                        if (st == 2) { if (R >= p.sl_upper) st = 3; else x = R; }
+                        if (st == 3) {
+                            if (L < p.sl_lower) L = p.sl_lower;
+                            if (R > p.sl_upper) R = p.sl_upper;
+                            x1 = rng_uniform_range(rng, L, R);
+                            x = x1;
+                        }
+                    }
+                    if (__all(st == 4)) break;
+                }
+                KLHR_WAVE_SYNC();
+                for (int i = l8; i < D; i += 8) {
+                    double2 v = TR[i];
+                    v.x = __dadd_rn(__dmul_rn(v.y, x1), v.x);          // theta = rho * x1 + theta
+                    TR[i] = v;
+                }
+                acc += (1.0 - acc) / (double)draw;
+                gevals += evals;
+                dg_zp = x1; dg_r = logy; dg_logu = L; dg_fun2 = R; dg_nfev1 = evals; dg_acc = 1;
+                KLHR_WAVE_SYNC();
+            }
+        } else
         // =============================================================== MH step (klhr_sinh.py:242-260)
         if (p.phases & PH_MH) {
             draw += 1;
@@ -724,7 +783,7 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
                                       [&](int i, double gi) { if ((i & 7) == l8) Z[i] = gi; }, lp_, gd_);
                     KLHR_WAVE_SYNC();
                     om_update_strided(p.omd_m + c * (long long)D, p.omd_v + c * (long long)D, omN, D, l8, TR, Z, true,
-                                      VARIANT == VAR_GAUSS ? INFINITY : (VARIANT == VAR_SUB ? p.grad_clip : p.scale_clip));   // klhr.py:216: raw gradient
+                                      (VARIANT == VAR_GAUSS || VARIANT == VAR_SLICE) ? INFINITY : (VARIANT == VAR_SUB ? p.grad_clip : p.scale_clip));   // klhr.py:216, slice.py:179: raw gradient
                     KLHR_WAVE_SYNC();
                 }
                 om_update_strided(p.om_m + c * (long long)D, p.om_v + c * (long long)D, omN, D, l8, TR, Z, false, 0.0);
@@ -758,6 +817,7 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
     {
         unsigned long long b = __ballot(!finite_theta);
         if (((b >> (grp << 3)) & 0xffULL) && l8 == 0) atomicOr(&p.status[c], 2);
+        if (VARIANT == VAR_SLICE && sl_capped && l8 == 0) atomicOr(&p.status[c], 4);
     }
     if (l8 == 0) {
         p.rng[c * 4 + 0] = rng.sh; p.rng[c * 4 + 1] = rng.sl; p.rng[c * 4 + 2] = rng.ih; p.rng[c * 4 + 3] = rng.il;

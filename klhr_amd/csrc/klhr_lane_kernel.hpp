@@ -69,7 +69,7 @@ __device__ inline void lane_direction(const KParams &p, long long c, double2 *TR
                     if (j < nc) {
                         double e = j == 0 ? e0[k] : (j == 1 ? e1[k] : evec[i * nc + j]);
                         if (pick >= 0) { if (j == pick) m = e; }
-                        else m += (p.variant == VAR_GAUSS ? ev[j] : pj[j]) * e;      // klhr.py:150
+                        else m += ((p.variant == VAR_GAUSS || p.variant == VAR_SLICE) ? ev[j] : pj[j]) * e;      // klhr.py:150
                     }
                 }
                 double r = m + sqrt(cv[k]) * Z[rk[k]];

@@ -503,3 +503,100 @@ def test_sub_free_running_vs_reference():
     bad = np.flatnonzero(err > 1e-6)
     first = int(bad[0]) if bad.size else 120
     assert np.array_equal(np.any(dr[1:first] != dr[:first - 1], axis=1), g["accept"][1:first])
+
+
+G13 = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "g13_slice_*_w*.npz")))
+
+
+def parse_g13(fn):
+    parts = fn[len("g13_slice_"):-4].split("_")
+    flags = {}
+    if "m2" in parts[3:]:
+        flags["eigen_method_one"] = False
+    if "s" in parts[3:]:
+        flags["scale_dir_cov"] = True
+    return parts[0], flags
+
+
+@pytest.mark.parametrize("fn", G13)
+def test_slice_variant_vs_oracle_and_reference(oracle, fn):
+    """Slice sampler (slice.py): every record of a golden trace becomes one GPU chain.  Direction draw and
+    streaming update are bit-exact vs the oracle as for the other variants; the slice step from the reference's rho must
+    consume the generator exactly like the reference (same number of stepping-out / shrinkage draws) and land on the same
+    point, except where a comparison g(x) <= log y is decided by the last bits of the log density."""
+    name, flags = parse_g13(fn)
+    g = golden(fn)
+    stem, data = model_spec(name)
+    M, warmup, seed = int(g["M"][0]), int(g["warmup"][0]), int(g["seed"][0])
+    M = min(M, 300)
+    # oracle, teacher-forced, to have the adaptation state before every record
+    c = oracle.SliceChain(stem, data, seed=seed, warmup=warmup, **flags)
+    fields = ["mean", "cov", "eigvecs", "eigvals", "om_m", "om_v", "pca_v"] + (["omd_m", "omd_v"] if flags.get("scale_dir_cov") else [])
+    before = {f: [] for f in fields}
+    after = {f: [] for f in fields}
+    cnt_before, cnt_after, rho_o, rng_dir, th_o, rng_o, ev_o = [], [], [], [], [], [], []
+    for m in range(M):
+        for f in fields:
+            before[f].append(c.get(f).copy())
+        cnt_before.append([m, c.get("om_N"), c.get("pca_n"), c.get("cidx")])
+        c.set("theta", g["theta_before"][m]); c.set("rng", g["state_before"][m])
+        rho_o.append(c.random_direction()); rng_dir.append(c.get("rng"))
+        e0 = c.slice_evals()
+        c.set("draw", m)
+        th_o.append(c.uni_slice(g["rho"][m])); rng_o.append(c.get("rng")); ev_o.append(c.slice_evals() - e0)
+        c.set("theta", g["theta_after"][m]); c.set("rng", g["state_after"][m])
+        c.adapt()
+        for f in fields:
+            after[f].append(c.get(f).copy())
+        cnt_after.append([m + 1, c.get("om_N"), c.get("pca_n"), c.get("cidx")])
+    s = make_sampler(stem, data, M, warmup=warmup, tol=1e-12, eigen_method_one=flags.get("eigen_method_one", True),
+                     scale_dir_cov=flags.get("scale_dir_cov", False), variant=3)
+    assert s.kernel_name() == "klhr_iter_kernel"
+    s.set("theta", g["theta_before"][:M]); s.set("rng", g["state_before"][:M])
+    for f in fields:
+        s.set(f, np.array(before[f]))
+    s.set("counters", np.array(cnt_before, dtype=np.int64))
+    rho = s.random_direction()
+    assert np.array_equal(s.get("rng"), np.array(rng_dir))
+    assert np.array_equal(rho, np.array(rho_o)), np.abs(rho - np.array(rho_o)).max()
+    # ---- the slice step from the reference's rho
+    ge0 = s.get("grad_evals").copy()
+    s.slice_step(g["rho"][:M])
+    th, rng, ev = s.get("theta"), s.get("rng"), s.get("grad_evals") - ge0
+    same_o = np.all(rng == np.array(rng_o), axis=1) & (ev == np.array(ev_o))
+    same_r = np.all(rng == g["state_after"][:M], axis=1) & (ev == g["evals"][:M])
+    assert same_o.mean() >= 0.99 and same_r.mean() >= 0.99, (same_o.mean(), same_r.mean())
+    assert np.allclose(th[same_o], np.array(th_o)[same_o], rtol=1e-12, atol=1e-13)
+    assert np.allclose(th[same_r], g["theta_after"][:M][same_r], rtol=1e-12, atol=1e-13)
+    assert np.all(s.get("counters")[:, 0] == np.arange(1, M + 1))
+    assert not s.get("status").any()
+    # ---- closure-or-update from the reference's theta: bit-exact vs the oracle
+    s.set("theta", g["theta_after"][:M]); s.set("rng", g["state_after"][:M])
+    s.adapt()
+    for f in fields:
+        if f.startswith("omd"):      # moments of the model gradient: device libm (exp) differs from glibc by ulps
+            assert np.allclose(s.get(f), np.array(after[f]), rtol=1e-12, atol=1e-13), f
+        else:
+            assert np.array_equal(s.get(f), np.array(after[f])), f
+    assert np.array_equal(s.get("counters"), np.array(cnt_after, dtype=np.int64))
+
+
+def test_slice_free_running_and_python_class():
+    """klhr_amd.Slice with the reference's constructor: its draw() loop follows the reference's own draw() until the
+    first window closure (nothing depends on CCIPCA before), and keeps sampling the right distribution after."""
+    from klhr_amd import BSModel, Slice
+    stan = os.path.join(os.path.dirname(GOLDEN), "..", "klhr_amd", "stan")
+    g = golden("g13_slice_funnel10_s0_w100.npz")
+    m = BSModel(os.path.join(stan, "funnel.stan"), os.path.join(stan, "funnel.json"))
+    algo = Slice(m, seed=0, warmup=100)
+    th = np.array([algo.draw() for _ in range(50)])
+    assert np.allclose(th, g["theta_after"][:50], rtol=1e-11, atol=1e-12)
+    assert algo.grad_evals == int(g["evals"][:50].sum())
+    assert algo.acceptance_probability == pytest.approx(1.0)
+    with pytest.raises(NotImplementedError):
+        Slice(m, seed=0, m=5)
+    # many chains on a 2-D standard normal: moments of the draws
+    mn = BSModel(os.path.join(stan, "normal.stan"), os.path.join(stan, "normal.json"))
+    many = Slice(mn, seed=3, warmup=100, chains=512)
+    d = many.draws(400)[150:]
+    assert abs(d.mean()) < 0.02 and abs(d.var() - 1.0) < 0.04
