@@ -14,10 +14,11 @@ import numpy as np
 from .bsmodel import BSModel
 from .klhr import KLHR
 from .klhr_sinh import KLHRSINH
+from .slice import Slice
 from .sub_klhr_sinh import SUBKLHRSINH
 
 STAN = Path(__file__).resolve().parent / "stan"
-SAMPLERS = {"klhr_sinh": KLHRSINH, "klhr": KLHR, "sub_klhr_sinh": SUBKLHRSINH}
+SAMPLERS = {"klhr_sinh": KLHRSINH, "klhr": KLHR, "sub_klhr_sinh": SUBKLHRSINH, "slice": Slice}
 
 
 @click.command()
@@ -41,7 +42,7 @@ def main(M, warmup, windowsize, windowscale, l, J, rep, verbose, scale_dir_cov, 
          outdir, no_plots, algorithm):
     if algorithm not in SAMPLERS:
         print(f"Unknown algorithm {algorithm}")
-        print("Available algorithms on the GPU path: klhr, klhr_sinh, sub_klhr_sinh")
+        print("Available algorithms: klhr, klhr_sinh, sub_klhr_sinh, or slice")
         sys.exit(0)
     bs_model = BSModel(stan_file=STAN / "ar1.stan", data_file=STAN / "ar1.json")
     algo = SAMPLERS[algorithm](bs_model, warmup=warmup, windowsize=windowsize, windowscale=windowscale, l=l, J=J,

@@ -12,6 +12,7 @@ import numpy as np
 from .bsmodel import BSModel
 from .klhr import KLHR
 from .klhr_sinh import KLHRSINH
+from .slice import Slice
 from .sub_klhr_sinh import SUBKLHRSINH
 
 STAN = Path(__file__).resolve().parent / "stan"
@@ -30,11 +31,11 @@ STAN = Path(__file__).resolve().parent / "stan"
 @click.option("--no-plots", is_flag=True)
 @click.argument("algorithm", type=str)
 def main(M, warmup, verbose, scale_dir_cov, overrelaxed, eigen_method_one, chains, seed, outdir, no_plots, algorithm):
-    if algorithm not in ("klhr_sinh", "klhr", "sub_klhr_sinh"):
+    if algorithm not in ("klhr_sinh", "klhr", "sub_klhr_sinh", "slice"):
         print(f"Unknown algorithm {algorithm}")
-        print("Available algorithms on the GPU path: klhr, klhr_sinh, sub_klhr_sinh")
+        print("Available algorithms: klhr, klhr_sinh, sub_klhr_sinh, or slice")
         sys.exit(0)
-    Sampler = {"klhr_sinh": KLHRSINH, "klhr": KLHR, "sub_klhr_sinh": SUBKLHRSINH}[algorithm]
+    Sampler = {"klhr_sinh": KLHRSINH, "klhr": KLHR, "sub_klhr_sinh": SUBKLHRSINH, "slice": Slice}[algorithm]
     bs_model = BSModel(stan_file=STAN / "funnel.stan", data_file=STAN / "funnel.json")
     algo = Sampler(bs_model, warmup=warmup, scale_dir_cov=scale_dir_cov, overrelaxed=overrelaxed,
                     eigen_method_one=eigen_method_one, chains=chains, seed=seed)

@@ -132,6 +132,11 @@ def test_experiment_harnesses_run(tmp_path):
     r = CliRunner().invoke(acc_main, ["-M", "300", "--seed", "2", "--outdir", str(tmp_path), "-v", "klhr_sinh"])
     assert r.exit_code == 0, r.output
     assert "final RMSE" in r.output
+    # the reference's fourth algorithm choice (experiment_funnel.py:42-43, experiment_accuracy.py:56-63)
+    r = CliRunner().invoke(funnel_main, ["-M", "150", "-w", "100", "--chains", "8", "--seed", "1", "--outdir", str(tmp_path), "--no-plots", "slice"])
+    assert r.exit_code == 0 and "v = theta[0]" in r.output, r.output
+    r = CliRunner().invoke(acc_main, ["-M", "300", "--seed", "2", "--outdir", str(tmp_path), "-v", "slice"])
+    assert r.exit_code == 0 and "final RMSE" in r.output, r.output
 
 
 def test_statistical_targets_funnel_and_normal():
