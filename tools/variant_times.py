@@ -5,7 +5,7 @@ import numpy as np
 from klhr_amd import _lib
 C=65536
 for name,kw in (("klhr_sinh",{}),("klhr_sinh overrelaxed",dict(overrelaxed=True)),("klhr (gauss)",dict(variant=1)),("klhr overrelaxed",dict(variant=1,overrelaxed=True)),
-                ("sub_klhr_sinh",dict(variant=2)),("sub overrelaxed",dict(variant=2,overrelaxed=True)),("eigen_method_one",dict(eigen_method_one=True)),("scale_dir_cov",dict(scale_dir_cov=True))):
+                ("sub_klhr_sinh",dict(variant=2)),("sub overrelaxed",dict(variant=2,overrelaxed=True)),("slice (octet kernel)",dict(variant=3,tol=1e-12,eigen_method_one=True)),("eigen_method_one",dict(eigen_method_one=True)),("scale_dir_cov",dict(scale_dir_cov=True))):
     s=_lib.Sampler(_lib.MODEL_IDS["funnel"],np.array([9.0]),C,warmup=100,**kw)
     s.seed(np.arange(C,dtype=np.uint64)); s.step(150)
     best=1e9
