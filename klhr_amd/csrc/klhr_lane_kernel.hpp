@@ -366,7 +366,12 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
     const bool diag = (p.flags & FLAG_DIAG) && !(p.phases & (PH_KL | PH_LINE));
     double *dd = p.d_diag + (active ? c : 0) * KLHR_NDIAG;
 
+#ifdef KLHR_STAMPS
+    unsigned long long stamp_t = __builtin_readcyclecounter(), st_dir = 0, st_line = 0, st_kl = 0, st_klsh = 0, st_adv = 0, st_mh = 0,
+                       st_adapt = 0, st_out = 0, st_trips = 0, st_shtrips = 0, st_kltrips = 0;
+#endif
     for (int iter = 0; iter < p.n_iters; ++iter) {
+        KLHR_STAMP(st_out);
         // =============================================================== direction
         if (active) {
             if (p.phases & PH_DIR) {
@@ -383,6 +388,7 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
             }
         }
 
+        KLHR_STAMP(st_dir);
         // =============================================================== fit
         if (p.phases & PH_FIT) {
             Opt o;
@@ -411,7 +417,12 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
                 const bool hit = !done && opt_cache_hit(o);
                 const bool ev1 = !done && !hit && o.n == 1;
                 const bool ev4 = !done && !hit && o.n != 1;
+                KLHR_STAMP(st_adv);
                 if (ev1) lane_eval_line<MODEL>(p, TR, o.xt[0], f, g);
+                KLHR_STAMP(st_line);
+#ifdef KLHR_STAMPS
+                st_trips++;
+#endif
                 if constexpr (VARIANT == VAR_GAUSS) {
                     if (ev4) lane_eval_kl_gauss<MODEL>(p, TR, o.xt, f, g);
                 } else {
@@ -425,6 +436,10 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
                     constexpr bool SUB = VARIANT == VAR_SUB;
                     const unsigned long long m4 = __ballot(ev4);
                     const int n4 = __popcll(m4);
+#ifdef KLHR_STAMPS
+                    if (n4 > 0) st_kltrips++;
+                    if (n4 > 0 && n4 <= 8) st_shtrips++;
+#endif
                     if (n4 > 8) {
                         if (ev4) {
                             const KLScal k = kl_scalars<SUB>(p, o.xt[1], o.xt[2], o.xt[3]);
@@ -438,6 +453,7 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
                             }
                             f = acc5[0]; g[0] = acc5[1]; g[1] = acc5[2]; g[2] = acc5[3]; g[3] = acc5[4];
                         }
+                        KLHR_STAMP(st_kl);
                     } else if (n4 > 0) {
                         const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m4 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m4, 0u));
                         if (ev4) {
@@ -468,6 +484,7 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
                                                   __dadd_rn(__dadd_rn(pp[20 + j], pp[25 + j]), __dadd_rn(pp[30 + j], pp[35 + j])));
                             f = r5[0]; g[0] = r5[1]; g[1] = r5[2]; g[2] = r5[3]; g[3] = r5[4];
                         }
+                        KLHR_STAMP(st_klsh);
                     }
                 }
                 if (!done) {
@@ -518,6 +535,7 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
             dp[0] = f; dp[1] = g[0]; dp[2] = g[1]; dp[3] = g[2]; dp[4] = g[3];
         }
 
+        KLHR_STAMP(st_adv);
         // =============================================================== MH step
         if ((p.phases & PH_MH) && active) {
             draw += 1;
@@ -556,6 +574,7 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
             if (diag) { dd[KLHR_D_ZP] = zp; dd[KLHR_D_R] = r; dd[KLHR_D_LOGU] = logu; dd[KLHR_D_ACCEPT] = a; }
         }
 
+        KLHR_STAMP(st_mh);
         // =============================================================== closure-or-update
         if ((p.phases & PH_ADAPT) && active) {
             bool closed = false;
@@ -593,6 +612,7 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
             }
         }
 
+        KLHR_STAMP(st_adapt);
         // =============================================================== draws: cooperative, coalesced store
         if (p.draws) {
             KLHR_WAVE_SYNC();
@@ -608,6 +628,14 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
         }
     }
 
+#ifdef KLHR_STAMPS
+    if (lane == 0 && (p.flags & FLAG_DIAG)) {      // diagnostic build: cycle totals of the wavefront's phases in its first chain's diag row
+        double *ds = p.d_diag + c0 * KLHR_NDIAG;
+        ds[0] = (double)st_dir; ds[1] = (double)st_line; ds[2] = (double)st_kl; ds[3] = (double)st_klsh; ds[4] = (double)st_adv;
+        ds[5] = (double)st_mh; ds[6] = (double)st_adapt; ds[7] = (double)st_out; ds[8] = (double)st_trips; ds[9] = (double)st_kltrips;
+        ds[10] = (double)st_shtrips;
+    }
+#endif
     // ---- store chain state
     KLHR_WAVE_SYNC();
     {
