@@ -348,6 +348,7 @@ static int run_phases(klhr_sampler *s, int phases, int64_t n_iters, int record_d
         kp.n_iters = (int)((n_iters - done) < chunk_max ? (n_iters - done) : chunk_max);
         if (record_diag) kp.flags |= FLAG_DIAG;
         kp.draws = record_draws ? s->d_draws + (size_t)done * s->C * s->D : nullptr;
+        if (getenv("KLHR_TRACE_LAUNCH")) fprintf(stderr, "[klhr] launch phases=%d n_iters=%d flags=%d chains=%d\n", kp.phases, kp.n_iters, kp.flags, kp.C);
         int rc = launch_iter(s, kp);
         if (rc) return rc;
         launches++;

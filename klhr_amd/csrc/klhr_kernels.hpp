@@ -38,6 +38,10 @@ enum { VAR_SINH = 0, VAR_GAUSS = 1, VAR_SUB = 2, VAR_SLICE = 3 };   // klhr_sinh
 // OnlinePCA's own tolerance: both samplers construct OnlinePCA(D, K=J, l=l) with its default tol = 1e-10
 // (klhr_sinh.py:62, klhr.py:63, onlinepca.py:5), independently of the sampler's `tol`.
 #define PCA_TOL 1e-10
+// Safety valve of the fit loops: SciPy's own limits (n*200 BFGS iterations, <= 100 DCSRCH + 10 wolfe2 + 100 zoom
+// evaluations each) bound the two fits of a draw by ~2e5 passes; a wavefront that exceeds this leaves the loop and flags
+// its unfinished chains (status bit 8), so that a kernel can never spin on the device.
+#define KLHR_MAX_PASSES 400000
 enum { FLAG_SCALE_DIR_COV = 1, FLAG_EIGEN_ONE = 2, FLAG_DIAG = 4, FLAG_DRAWS = 8, FLAG_OVERRELAXED = 16 };
 
 struct KParams {
@@ -542,7 +546,7 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
     double eta[4] = {0, 0, 0, 0};
     double dg_x0 = 0, dg_mode = 0, dg_hinv1 = 0, dg_fun2 = 0, dg_init[4] = {0, 0, 0, 0}, dg_zp = 0, dg_r = 0, dg_logu = 0;
     int dg_nfev1 = 0, dg_nit1 = 0, dg_st1 = 0, dg_nfev2 = 0, dg_nit2 = 0, dg_st2 = 0, dg_acc = 0, dg_fb = 0, dg_pass = 0;
-    bool sl_capped = false;
+    bool sl_capped = false, fit_capped = false;
 
 #ifdef KLHR_STAMPS
     unsigned long long stamp_t = __builtin_readcyclecounter(), st_dir = 0, st_eval = 0, st_adv = 0, st_mh = 0, st_adapt = 0, st_out = 0, st_idle = 0;
@@ -580,6 +584,7 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
                 opt_begin(o, 1, x0v, 1e-5);
             }
             bool done = false;
+            int trips = 0;
             dg_pass = 0;
             for (;;) {
                 double f = 0, g[4] = {0, 0, 0, 0};
@@ -637,8 +642,9 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
                     }
                     KLHR_STAMP(st_adv);
                 }
-                if (__all(done)) break;
+                if (__all(done) || ++trips > KLHR_MAX_PASSES) break;
             }
+            if (!done) { fit_capped = true; for (int k = 0; k < 4; k++) eta[k] = o.xk[k]; }
             if (p.flags & FLAG_DIAG) {
                 const double e_sel = l8 == 0 ? eta[0] : (l8 == 1 ? eta[1] : (l8 == 2 ? eta[2] : eta[3]));
                 if (l8 < 4) p.d_eta[c * 4 + l8] = e_sel;
@@ -818,6 +824,7 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
         unsigned long long b = __ballot(!finite_theta);
         if (((b >> (grp << 3)) & 0xffULL) && l8 == 0) atomicOr(&p.status[c], 2);
         if (VARIANT == VAR_SLICE && sl_capped && l8 == 0) atomicOr(&p.status[c], 4);
+        if (fit_capped && l8 == 0) atomicOr(&p.status[c], 8);
     }
     if (l8 == 0) {
         p.rng[c * 4 + 0] = rng.sh; p.rng[c * 4 + 1] = rng.sl; p.rng[c * 4 + 2] = rng.ih; p.rng[c * 4 + 3] = rng.il;

@@ -362,6 +362,7 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
     KLHR_WAVE_SYNC();
 
     double eta[4] = {0, 0, 0, 0};
+    bool fit_capped = false;            // KLHR_MAX_PASSES reached (klhr_kernels.hpp)
     // diagnostics go straight to memory when requested (wave-uniform flag): they are not carried in registers
     const bool diag = (p.flags & FLAG_DIAG) && !(p.phases & (PH_KL | PH_LINE));
     double *dd = p.d_diag + (active ? c : 0) * KLHR_NDIAG;
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
                 opt_begin(o, 1, x0v, 1e-5);
             }
             bool done = !active;
-            int npass = 0;
+            int npass = 0, trips = 0;
             for (;;) {
                 double f = 0, g[4] = {0, 0, 0, 0};
                 const bool hit = !done && opt_cache_hit(o);
@@ -515,8 +516,9 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
                         }
                     }
                 }
-                if (__all(done)) break;
+                if (__all(done) || ++trips > KLHR_MAX_PASSES) break;
             }
+            if (!done) { fit_capped = true; for (int k = 0; k < 4; k++) eta[k] = o.xk[k]; }
             if (active && (p.flags & FLAG_DIAG)) {
                 for (int k = 0; k < 4; k++) p.d_eta[c * 4 + k] = eta[k];
             }
@@ -652,6 +654,7 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
         bool fin = true;
         for (int i = 0; i < D; i++) if (!isfinite(TR[i].x)) fin = false;
         if (!fin) atomicOr(&p.status[c], 2);
+        if (fit_capped) atomicOr(&p.status[c], 8);
         p.rng[c * 4 + 0] = rng.sh; p.rng[c * 4 + 1] = rng.sl; p.rng[c * 4 + 2] = rng.ih; p.rng[c * 4 + 3] = rng.il;
         p.counters[c * 4 + 0] = draw; p.counters[c * 4 + 1] = omN; p.counters[c * 4 + 2] = pcan; p.counters[c * 4 + 3] = cidx;
         p.acc[c] = acc;
