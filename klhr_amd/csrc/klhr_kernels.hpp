@@ -181,11 +181,18 @@ __device__ inline double gauss_zp(Pcg64 &rng, const double *eta, int K, double s
     }
 }
 // The over-relaxed proposals run once per iteration but, inlined, their loops and the Phi / Phi^-1 expansions sit in the
-// register allocation of the whole kernel (measured: ~1.4 KB of scratch per lane, -17 % throughput).  Out-of-line
-// wrappers with everything passed BY VALUE keep that code in its own frame; by-reference arguments would pin the
-// generator state to memory for the whole kernel.
+// register allocation of the whole kernel (~1.4 KB of scratch per lane, -17 % throughput with overrelaxed=True).
+// Out-of-line by-value wrappers (-DKLHR_OR_NOINLINE) remove that cost, BUT one instantiation built that way
+// (klhr_iter_kernel<glmm-poisson, over-relaxed, SUBKLHRSINH>) faulted on the device in tools/stress.py — a function call
+// out of a 100 KB kernel that also spills is not something this toolchain gets right every time — so the default is the
+// inlined form and the out-of-line form stays an experiment.
+#ifdef KLHR_OR_NOINLINE
+#define KLHR_OR_ATTR __attribute__((noinline))
+#else
+#define KLHR_OR_ATTR __forceinline__
+#endif
 struct ZpOut { double zp; Pcg64 rng; };
-__device__ __attribute__((noinline)) ZpOut overrelaxed_zp_call(Pcg64 rng, double e0, double e1, double e2, double e3, int K, double tol,
+__device__ KLHR_OR_ATTR ZpOut overrelaxed_zp_call(Pcg64 rng, double e0, double e1, double e2, double e3, int K, double tol,
                                                                double sc, bool sub) {
     const double eta[4] = {e0, e1, e2, e3};
     ZpOut o;
@@ -193,7 +200,7 @@ __device__ __attribute__((noinline)) ZpOut overrelaxed_zp_call(Pcg64 rng, double
     o.rng = rng;
     return o;
 }
-__device__ __attribute__((noinline)) ZpOut gauss_overrelaxed_zp_call(Pcg64 rng, double e0, double e1, int K, double sc) {
+__device__ KLHR_OR_ATTR ZpOut gauss_overrelaxed_zp_call(Pcg64 rng, double e0, double e1, int K, double sc) {
     const double eta[4] = {e0, e1, 0.0, 0.0};
     ZpOut o;
     o.zp = gauss_zp<true>(rng, eta, K, sc);
