@@ -53,3 +53,28 @@ def test_full_size_population(oracle, name, C, n):
             sh.step(n)
             for f in ("theta", "rng", "acc", "grad_evals"):
                 assert np.array_equal(sh.get(f), st[f][r * h:(r + 1) * h]), (f, r)
+
+
+@pytest.mark.parametrize("name", ["funnel10", "illnormal100", "glmm45", "earnings"])
+def test_odd_chain_counts_every_variant(name):
+    """Partially filled wavefronts (1, 9, 65 chains) for every sampler variant with and without over-relaxation: states stay
+    finite, status flags clear, and the first chain does not depend on how many others ran beside it.  (tools/stress.py
+    is the larger, process-isolated version of this net.)"""
+    stem, data = model_spec(name)
+    n = 40 if name == "glmm45" else 110
+    for variant in (0, 1, 2, 3):
+        for over in ((False,) if variant == 3 else (False, True)):
+            first = None
+            for C in (1, 9, 65):
+                kw = dict(warmup=100, variant=variant, overrelaxed=over)
+                if variant == 3:
+                    kw["tol"] = 1e-12
+                s = make_sampler(stem, data, C, **kw)
+                s.seed(np.arange(C, dtype=np.uint64) + 17)
+                s.step(n)
+                th = s.get("theta")
+                assert np.isfinite(th).all() and not s.get("status").any(), (name, variant, over, C)
+                if first is None:
+                    first = th[0].copy()
+                else:
+                    assert np.array_equal(th[0], first), (name, variant, over, C)
