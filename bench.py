@@ -168,7 +168,7 @@ def main():
                                   "estimated_on_chains": nsub}
         if world == 1 and not args.no_cpu_baseline:
             threads = min(os.cpu_count() or 1, 16)
-            n_cpu_chains, cpu_iters = 64 * threads, 200
+            n_cpu_chains, cpu_iters = 256 * threads, 200        # ~1.2 s wall on 16 threads = ~19 s of CPU work
             v = cpu_baseline(n_cpu_chains, 100, cpu_iters, threads)
             out["cpu_baseline"] = {"value": v, "unit": "iterations/s", "cores": threads, "kind": "port",
                                    "sample": f"CPU oracle (C restatement of the reference path, OpenMP over chains): {n_cpu_chains} funnel-10D chains x {cpu_iters} draws after 100 warmup draws"}
