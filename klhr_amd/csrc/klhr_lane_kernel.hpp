@@ -284,30 +284,45 @@ __device__ __forceinline__ void lane_eval_kl(const KParams &p, const double2 *TR
     for (int j = 0; j < 4; j++) g[j] = __dadd_rn(P0[j + 1], P1[j + 1]);
 }
 
-// KLHR objective (klhr.py:109-124) for this lane's chain: 8 nodes y_n = s x_n + m, raw gradient
+// KLHR objective (klhr.py:109-124): 8 nodes y_n = s x_n + m, raw gradient — as node groups with the same fixed summation
+// tree as lane_kl_group, so that the tail of a KLHR fit can be node-shared too.  part = (sum w logp, sum w g.rho,
+// sum w g.rho x_n s) over the group's nodes; xq / wq point at the group's first node.
+#pragma clang fp contract(off)
+template <int MODEL, int G>
+__device__ __forceinline__ void lane_gauss_group(const KParams &p, const double2 *TR, double m, double s_, const double *xq, const double *wq,
+                                                 double (&part)[5]) {
+    double t[G], logp[G], gdot[G];
+#pragma unroll
+    for (int n = 0; n < G; n++) t[n] = fma(s_, xq[n], m);
+    model_eval_nv<MODEL, G>(p.md, TR, t, INFINITY, logp, gdot);
+    double c[G][3];
+#pragma unroll
+    for (int n = 0; n < G; n++) {
+        const double wgr = wq[n] * gdot[n];
+        c[n][0] = wq[n] * logp[n];
+        c[n][1] = wgr;
+        c[n][2] = (wgr * xq[n]) * s_;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        if constexpr (G == 4) part[j] = (c[0][j] + c[1][j]) + (c[2][j] + c[3][j]);
+        else if constexpr (G == 2) part[j] = c[0][j] + c[1][j];
+        else part[j] = c[0][j];
+    }
+    part[3] = part[4] = 0.0;
+}
+#pragma clang fp contract(fast)
+
 template <int MODEL>
 __device__ __forceinline__ void lane_eval_kl_gauss(const KParams &p, const double2 *TR, const double *xt, double &f, double *g) {
-    constexpr int NVG = KLHR_NVG;
     const double s_ = exp(clipc(xt[1], p.scale_clip));
-    double out = 0.0, g0 = 0.0, g1 = 0.0;
-#pragma unroll
-    for (int h = 0; h < 8 / NVG; h++) {
-        double t[NVG], logp[NVG], gdot[NVG];
-#pragma unroll
-        for (int n = 0; n < NVG; n++) t[n] = s_ * p.xq[h * NVG + n] + xt[0];
-        model_eval_nv<MODEL, NVG>(p.md, TR, t, INFINITY, logp, gdot);
-#pragma unroll
-        for (int n = 0; n < NVG; n++) {
-            const double w = p.wq[h * NVG + n];
-            out += w * logp[n];
-            const double wgr = w * gdot[n];
-            g0 += wgr;
-            g1 += wgr * p.xq[h * NVG + n] * s_;
-        }
-    }
-    out += xt[1];
-    g1 += 1;
-    f = -out; g[0] = -g0; g[1] = -g1; g[2] = g[3] = 0.0;
+    double P0[5], P1[5];
+    lane_gauss_group<MODEL, 4>(p, TR, xt[0], s_, p.xq, p.wq, P0);
+    lane_gauss_group<MODEL, 4>(p, TR, xt[0], s_, p.xq + 4, p.wq + 4, P1);
+    f = -(__dadd_rn(P0[0], P1[0]) + xt[1]);
+    g[0] = -__dadd_rn(P0[1], P1[1]);
+    g[1] = -(__dadd_rn(P0[2], P1[2]) + 1.0);
+    g[2] = g[3] = 0.0;
 }
 
 template <int MODEL>
@@ -332,7 +347,7 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
     double2 *TR = reinterpret_cast<double2 *>(lds + (size_t)lane * p.S);
     double *Z = lds + (size_t)lane * p.S + 2 * (size_t)D;
     double *shx = lds + (size_t)64 * p.S;            // node-shared evaluation: see the fit loop
-    if (lane < 8) { shx[LANE_Q + lane] = p.asx[lane]; shx[LANE_Q + 8 + lane] = p.wq[lane]; }
+    if (lane < 8) { shx[LANE_Q + lane] = VARIANT == VAR_GAUSS ? p.xq[lane] : p.asx[lane]; shx[LANE_Q + 8 + lane] = p.wq[lane]; }
 
     // ---- cooperative, coalesced load of the block's theta rows into LDS
     {
@@ -424,9 +439,7 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
 #ifdef KLHR_STAMPS
                 st_trips++;
 #endif
-                if constexpr (VARIANT == VAR_GAUSS) {
-                    if (ev4) lane_eval_kl_gauss<MODEL>(p, TR, o.xt, f, g);
-                } else {
+                {
                     // ---- KL evaluation, node-shared in the tail of the fit.
                     // Chains finish their fits after different numbers of evaluations (mean ~20 passes, slowest of 64
                     // ~30; in 40 % of the passes at most 8 chains of the wavefront are still fitting).  With n4 <= 8
@@ -434,7 +447,7 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
                     // the chain ranked j / 8 among the requesters, reading that chain's (theta, rho) from its LDS
                     // region, and the owner adds the 8 partials in the fixed tree of lane_kl_group.  (Serving 9..32
                     // requesters with 4 or 2 lanes each was measured too: such passes are rare, no gain.)
-                    constexpr bool SUB = VARIANT == VAR_SUB;
+                    constexpr bool SUB = VARIANT == VAR_SUB, GAUSS = VARIANT == VAR_GAUSS;
                     const unsigned long long m4 = __ballot(ev4);
                     const int n4 = __popcll(m4);
 #ifdef KLHR_STAMPS
@@ -443,16 +456,19 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
 #endif
                     if (n4 > 8) {
                         if (ev4) {
-                            const KLScal k = kl_scalars<SUB>(p, o.xt[1], o.xt[2], o.xt[3]);
+                            const KLScal k = kl_scalars<SUB>(p, o.xt[1], o.xt[2], o.xt[3]);      // (s_ = exp(clip(eta1)) serves KLHR)
+                            const double sg = GAUSS ? exp(clipc(o.xt[1], p.scale_clip)) : 0.0;
                             double acc5[5] = {0, 0, 0, 0, 0};
 #pragma unroll 1
                             for (int h = 0; h < 2; h++) {
                                 double part[5];
-                                lane_kl_group<MODEL, SUB, 4>(p, TR, o.xt[0], k, shx + LANE_Q + 4 * h, shx + LANE_Q + 8 + 4 * h, part);
+                                if constexpr (GAUSS) lane_gauss_group<MODEL, 4>(p, TR, o.xt[0], sg, shx + LANE_Q + 4 * h, shx + LANE_Q + 8 + 4 * h, part);
+                                else lane_kl_group<MODEL, SUB, 4>(p, TR, o.xt[0], k, shx + LANE_Q + 4 * h, shx + LANE_Q + 8 + 4 * h, part);
 #pragma unroll
                                 for (int j = 0; j < 5; j++) acc5[j] = h == 0 ? part[j] : __dadd_rn(acc5[j], part[j]);
                             }
-                            f = acc5[0]; g[0] = acc5[1]; g[1] = acc5[2]; g[2] = acc5[3]; g[3] = acc5[4];
+                            if constexpr (GAUSS) { f = -(acc5[0] + o.xt[1]); g[0] = -acc5[1]; g[1] = -(acc5[2] + 1.0); g[2] = g[3] = 0.0; }
+                            else { f = acc5[0]; g[0] = acc5[1]; g[1] = acc5[2]; g[2] = acc5[3]; g[3] = acc5[4]; }
                         }
                         KLHR_STAMP(st_kl);
                     } else if (n4 > 0) {
@@ -468,10 +484,13 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
                             const int ow = reinterpret_cast<const int *>(shx + LANE_OWN)[r];
                             const double x0 = shx[LANE_XT + ow * 4], x1 = shx[LANE_XT + ow * 4 + 1], x2 = shx[LANE_XT + ow * 4 + 2],
                                          x3 = shx[LANE_XT + ow * 4 + 3];
-                            const KLScal k = kl_scalars<SUB>(p, x1, x2, x3);
                             const double2 *TRo = reinterpret_cast<const double2 *>(lds + (size_t)ow * p.S);
                             double part[5];
-                            lane_kl_group<MODEL, SUB, 1>(p, TRo, x0, k, shx + LANE_Q + node, shx + LANE_Q + 8 + node, part);
+                            if constexpr (GAUSS) lane_gauss_group<MODEL, 1>(p, TRo, x0, exp(clipc(x1, p.scale_clip)), shx + LANE_Q + node, shx + LANE_Q + 8 + node, part);
+                            else {
+                                const KLScal k = kl_scalars<SUB>(p, x1, x2, x3);
+                                lane_kl_group<MODEL, SUB, 1>(p, TRo, x0, k, shx + LANE_Q + node, shx + LANE_Q + 8 + node, part);
+                            }
 #pragma unroll
                             for (int j = 0; j < 5; j++) shx[LANE_PART + lane * 5 + j] = part[j];
                         }
@@ -483,7 +502,8 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
                             for (int j = 0; j < 5; j++)
                                 r5[j] = __dadd_rn(__dadd_rn(__dadd_rn(pp[j], pp[5 + j]), __dadd_rn(pp[10 + j], pp[15 + j])),
                                                   __dadd_rn(__dadd_rn(pp[20 + j], pp[25 + j]), __dadd_rn(pp[30 + j], pp[35 + j])));
-                            f = r5[0]; g[0] = r5[1]; g[1] = r5[2]; g[2] = r5[3]; g[3] = r5[4];
+                            if constexpr (GAUSS) { f = -(r5[0] + o.xt[1]); g[0] = -r5[1]; g[1] = -(r5[2] + 1.0); g[2] = g[3] = 0.0; }
+                            else { f = r5[0]; g[0] = r5[1]; g[1] = r5[2]; g[2] = r5[3]; g[3] = r5[4]; }
                         }
                         KLHR_STAMP(st_klsh);
                     }

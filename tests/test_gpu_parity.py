@@ -262,7 +262,7 @@ def test_chunked_launches_equal_single_launch(oracle):
         assert np.array_equal(a.get(f), b.get(f)), f
 
 
-@pytest.mark.parametrize("name,variant", [("funnel10", 0), ("earnings", 0), ("funnel10", 2)])
+@pytest.mark.parametrize("name,variant", [("funnel10", 0), ("earnings", 0), ("funnel10", 2), ("funnel10", 1)])
 def test_chain_results_do_not_depend_on_wavefront_company(oracle, name, variant):
     """A chain is a pure function of its seed and the configuration: its draws are bit-identical whether it runs alone,
     among 7 or among 63 other chains.  (The lane kernel lets idle lanes evaluate quadrature-node groups for chains that
