@@ -124,7 +124,7 @@ KLHR_API int klhr_adapt(klhr_sampler *s);
 /* Slice sampler (variant 3) — replaces Slice.__init__'s w / lower / upper (slice.py:19-22; m = inf only: the reference's
  * finite-m branch refers to undefined names and cannot run) and Slice._uni_slice(rho) (slice.py:86-141, also _draw += 1).
  * max_evals caps the log-density evaluations of one draw (the reference loops forever on a density that never
- * compares); reaching it sets bit 4 of the chain's status.  klhr_step / klhr_random_direction / klhr_adapt serve
+ * compares); reaching it sets value 4 (bit 2) in the chain's status.  klhr_step / klhr_random_direction / klhr_adapt serve
  * draw() (slice.py:160-183) as for the other variants; grad_evals counts log-density evaluations.               */
 KLHR_API int klhr_set_slice(klhr_sampler *s, double w, double lower, double upper, int64_t max_evals);
 KLHR_API int klhr_slice_step(klhr_sampler *s, const double *rho);
@@ -157,7 +157,7 @@ enum klhr_field {
     KLHR_F_RHO = 14,       /* double  C×D  last direction (record_diag) */
     KLHR_F_ETA = 15,       /* double  C×4  last fitted eta (record_diag) */
     KLHR_F_DIAG = 16,      /* double  C×KLHR_NDIAG (record_diag), layout below */
-    KLHR_F_STATUS = 17,    /* int32   C    bit0 init failed, bit1 theta non-finite */
+    KLHR_F_STATUS = 17,    /* int32   C    bit0 (1) init failed, bit1 (2) theta non-finite, bit2 (4) slice evaluation cap, bit3 (8) fit safety valve */
     KLHR_F_KSTATE = 18     /* double  C×4  KLHR variant: [Smoother x, Smoother count, current K, moved flag] (klhr.py:212-221) */
 };
 /* KLHR_F_DIAG columns */

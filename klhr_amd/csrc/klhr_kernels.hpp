@@ -40,7 +40,7 @@ enum { VAR_SINH = 0, VAR_GAUSS = 1, VAR_SUB = 2, VAR_SLICE = 3 };   // klhr_sinh
 #define PCA_TOL 1e-10
 // Safety valve of the fit loops: SciPy's own limits (n*200 BFGS iterations, <= 100 DCSRCH + 10 wolfe2 + 100 zoom
 // evaluations each) bound the two fits of a draw by ~2e5 passes; a wavefront that exceeds this leaves the loop and flags
-// its unfinished chains (status bit 8), so that a kernel can never spin on the device.
+// its unfinished chains (status value 8), so that a kernel can never spin on the device.
 #define KLHR_MAX_PASSES 400000
 enum { FLAG_SCALE_DIR_COV = 1, FLAG_EIGEN_ONE = 2, FLAG_DIAG = 4, FLAG_DRAWS = 8, FLAG_OVERRELAXED = 16 };
 
