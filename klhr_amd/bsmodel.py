@@ -14,7 +14,8 @@ import numpy as np
 from . import _lib
 
 _STEMS = {"funnel": "funnel", "funnel-100": "funnel", "ill-normal": "ill-normal", "glmm-poisson": "glmm-poisson",
-          "normal": "normal", "normal-100": "normal", "ar1": "ar1", "earnings": "earnings"}
+          "normal": "normal", "normal-100": "normal", "ar1": "ar1", "earnings": "earnings",
+          "one_normal": "normal"}        # stan/one_normal.stan (slice.py:193): `real y; y ~ normal(0, 1)` = normal with D = 1
 
 
 def pack_model_data(stem, data):
@@ -48,6 +49,8 @@ class BSModel:
         if data is None:
             with open(data_file) as f:
                 data = json.load(f)
+        if stem == "one_normal":
+            data = dict(data, D=1)
         self.data = data
         self.model_id = _lib.MODEL_IDS[self.stem]
         self.model_data = pack_model_data(self.stem, data)

@@ -145,13 +145,13 @@ static int dalloc(klhr_sampler *s, T **p, size_t n) {
 static int reset_state(klhr_sampler *s) {
     KParams &k = s->kp;
     const size_t C = s->C, D = s->D, nc = s->ncol, J = s->cfg.J;
-    std::vector<double> ones(C * D, 1.0);
+    std::vector<double> ones(C * (D > nc ? D : nc), 1.0);        // cov (C x D) and eigvals (C x ncol; ncol may exceed D)
     std::vector<int> ident(C * D);
     for (size_t c = 0; c < C; c++)
         for (size_t i = 0; i < D; i++) ident[c * D + i] = (int)i;
     HIPCHECK(s, hipMemcpyAsync(k.cov, ones.data(), C * D * 8, hipMemcpyHostToDevice, s->stream));
     HIPCHECK(s, hipMemcpyAsync(k.rank, ident.data(), C * D * 4, hipMemcpyHostToDevice, s->stream));
-    HIPCHECK(s, hipMemcpyAsync(k.eigvals, ones.data(), C * nc * 8 <= C * D * 8 ? C * nc * 8 : 0, hipMemcpyHostToDevice, s->stream));
+    HIPCHECK(s, hipMemcpyAsync(k.eigvals, ones.data(), C * nc * 8, hipMemcpyHostToDevice, s->stream));
     HIPCHECK(s, hipMemsetAsync(k.theta, 0, C * D * 8, s->stream));
     HIPCHECK(s, hipMemsetAsync(k.mean, 0, C * D * 8, s->stream));
     HIPCHECK(s, hipMemsetAsync(k.eigvecs, 0, C * D * nc * 8, s->stream));

@@ -341,3 +341,30 @@ def test_two_ranks_on_the_device_match_one_rank(tmp_path):
             assert np.allclose(both["mean50"], mean50, rtol=1e-11, atol=1e-13)
             assert np.allclose(both["cov50"], cov50, rtol=1e-9, atol=1e-13)
             assert np.isfinite(both["theta"]).all()
+
+
+def test_one_normal_like_slice_main():
+    """slice.py:185-208 (`__main__`): Slice on stan/one_normal (a 1-D standard normal), 10 000 draws, mean and sd of the
+    draws; the same 1-D target through KLHRSINH."""
+    from klhr_amd import BSModel, KLHRSINH, Slice
+    m = BSModel(os.path.join(STAN, "one_normal.stan"), os.path.join(STAN, "one_normal.json"))
+    assert m.dim() == 1
+    draws = Slice(m, seed=4).sample(10_000)
+    assert draws.shape == (10_000, 1) and abs(np.mean(draws)) < 0.06 and abs(np.std(draws, ddof=1) - 1.0) < 0.05
+    ks = KLHRSINH(m, seed=4, warmup=100, overrelaxed=False, chains=256)
+    assert np.all(ks._sampler.get("eigvals") == 1.0)            # J = 2 eigenvalue slots although D = 1 (klhr_sinh.py:66)
+    many = ks.draws(300)[120:]
+    assert abs(many.mean()) < 0.03 and abs(many.std() - 1.0) < 0.04
+    # ncol = J + 1 > D (eigen_method_one on a 2-D target): the extra eigenvalue slot starts at 1 and is never overwritten by a
+    # window closure (klhr_sinh.py:64-66,276-277), exactly as in the oracle
+    from oracle import oracle as O
+    m2 = BSModel(os.path.join(STAN, "normal.stan"), os.path.join(STAN, "normal.json"))
+    k2 = KLHRSINH(m2, seed=7, warmup=100, overrelaxed=False, eigen_method_one=True)
+    c2 = O.Chain("normal", {"D": 2}, seed=7, warmup=100, eigen_method_one=True)
+    assert np.array_equal(k2._sampler.get("eigvals")[0], [1.0, 1.0, 1.0])
+    th = np.array([k2.draw() for _ in range(51)])
+    tho = c2.draw_many(51)
+    assert np.allclose(th[:50], tho[:50], rtol=1e-8, atol=1e-9)
+    ev, evo = k2._sampler.get("eigvals")[0], c2.get("eigvals")
+    assert ev[2] == 1.0 and evo[2] == 1.0 and np.allclose(ev[:1], evo[:1], rtol=1e-6)
+
