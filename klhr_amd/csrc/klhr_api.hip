@@ -276,16 +276,17 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
     TRY(dalloc(s, &k.d_rho, C * D)); TRY(dalloc(s, &k.d_eta, C * 4)); TRY(dalloc(s, &k.d_diag, C * KLHR_NDIAG));
     TRY(dalloc(s, &k.kstate, C * 4));
     k.warmup = cfg->warmup; k.windowsize = cfg->windowsize;
-    int64_t cl[40];
-    int ncl = klhr_window_closures(cfg->warmup, cfg->windowsize, cfg->windowscale, cl, 40);
-    if (ncl > 40) { s->err = "klhr_create: more than 40 adaptation windows"; return bail(KLHR_ERR_ARG); }
+    // window-closure draws (windowedadaptation.py:22-37): any number of them (windowscale = 1 gives warmup / windowsize)
+    int ncl = klhr_window_closures(cfg->warmup, cfg->windowsize, cfg->windowscale, nullptr, 0);
+    if (ncl < 0 || ncl > (1 << 20)) { s->err = "klhr_create: bad adaptation-window schedule"; return bail(KLHR_ERR_ARG); }
+    std::vector<int64_t> cl((size_t)(ncl > 0 ? ncl : 1), 0);
+    if (ncl > 0) klhr_window_closures(cfg->warmup, cfg->windowsize, cfg->windowscale, cl.data(), ncl);
     k.nclos = ncl;
     {
         long long *d_cl = nullptr;
-        TRY(dalloc(s, &d_cl, 40));
-        long long hcl[40] = {0};
-        for (int i = 0; i < ncl; i++) hcl[i] = cl[i];
-        TRY(hip_try(hipMemcpy(d_cl, hcl, sizeof hcl, hipMemcpyHostToDevice), "hipMemcpy closures"));
+        TRY(dalloc(s, &d_cl, cl.size()));
+        std::vector<long long> hcl(cl.begin(), cl.end());
+        TRY(hip_try(hipMemcpy(d_cl, hcl.data(), hcl.size() * sizeof(long long), hipMemcpyHostToDevice), "hipMemcpy closures"));
         k.closures = d_cl;
     }
     TRY(reset_state(s));

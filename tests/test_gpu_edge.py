@@ -52,3 +52,17 @@ def test_funnel_dimensions_around_kernel_boundaries(oracle):
         [c.draw() for _ in range(3)]
         assert np.allclose(s.get("cov")[0], c.get("cov"), rtol=1e-5, atol=1e-9), Da
         assert not s.get("status").any(), Da
+
+
+def test_window_schedules(oracle):
+    """WindowedAdaptation corner cases (no window at all, warmup == windowsize, windowscale 1 with 80 windows, closures at
+    the last warm-up draw): after 230 draws the bookkeeping (draw, OnlineMoments N, CCIPCA n, window index) equals the oracle's."""
+    for warmup, ws, wsc in itertools.product((0, 10, 49, 50, 51, 100, 149, 150, 151, 400), (5, 50, 60), (1, 2, 3)):
+        kw = dict(warmup=warmup, windowsize=ws, windowscale=wsc)
+        c = oracle.Chain("funnel", {"D": 9}, seed=5, **kw)
+        s = make_sampler("funnel", {"D": 9}, 2, **kw)
+        s.seed(np.array([5, 6], dtype=np.uint64))
+        s.step(230)
+        c.draw_many(230)
+        assert list(s.get("counters")[0]) == [230, int(c.get("om_N")), int(c.get("pca_n")), int(c.get("cidx"))], (warmup, ws, wsc)
+        assert np.isfinite(s.get("theta")).all()
