@@ -680,7 +680,7 @@ extern "C" int klhr_pool_stats(klhr_sampler *s, double *out, size_t n_out) {
     HIPCHECK(s, hipSetDevice(s->cfg.device));
     double *d_o = nullptr;
     HIPCHECK(s, hipMalloc((void **)&d_o, n_out * 8));
-    hipLaunchKernelGGL(klhr_pool_kernel, dim3(s->D), dim3(256), 0, s->stream, s->kp.om_m, s->kp.om_v, s->kp.counters, s->C, s->D, d_o);
+    hipLaunchKernelGGL(klhr_pool_kernel, dim3(s->D), dim3(256), 0, s->stream, s->kp.om_m, s->kp.om_v, s->kp.counters, s->kp.status, s->C, s->D, d_o);
     int rc = 0;
     { hipError_t e = hipGetLastError(); if (e != hipSuccess) { s->err = hipGetErrorString(e); rc = KLHR_ERR_HIP; } }
     if (!rc) rc = d2h(s, out, d_o, n_out * 8);
@@ -729,7 +729,7 @@ extern "C" int klhr_pool_gram(klhr_sampler *s, int64_t first_iter, int64_t n_ite
         rps = (rps + 3) / 4 * 4;
         slabs = (nrows + rps - 1) / rps;
         const double *X = s->d_draws + (size_t)first_iter * s->C * D;
-        hipLaunchKernelGGL(klhr_gram_mfma_kernel, dim3(tiles * tiles, (unsigned)slabs), dim3(64), 0, s->stream, X, nrows, D, Dp, rps, d_G);
+        hipLaunchKernelGGL(klhr_gram_mfma_kernel, dim3(tiles * tiles, (unsigned)slabs), dim3(64), 0, s->stream, X, nrows, D, Dp, rps, s->kp.status, s->C, d_G);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { s->err = hipGetErrorString(e); rc = KLHR_ERR_HIP; }
     }

@@ -1019,10 +1019,12 @@ __global__ void klhr_rank_kernel(const double *cov, int *rank, int C, int D) {
 }
 
 // pooled-adaptation sufficient statistics over this GPU's chains: out = [n, sum m_i (D), sum (v_i + m_i^2) (D)]
-__global__ void klhr_pool_kernel(const double *om_m, const double *om_v, const long long *counters, int C, int D, double *out) {
+// (chains whose state has gone non-finite — status bit 1, the reference's own failure mode — are left out of the pool)
+__global__ void klhr_pool_kernel(const double *om_m, const double *om_v, const long long *counters, const int *status, int C, int D, double *out) {
     const int i = blockIdx.x;        // coordinate
     double sm = 0, sq = 0, sn = 0;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        if (status[c] & 2) continue;
         double n = (double)counters[c * 4 + 1];
         double m = om_m[(long long)c * D + i], v = om_v[(long long)c * D + i];
         sm += n * m;
@@ -1048,7 +1050,7 @@ __global__ void klhr_pool_kernel(const double *om_m, const double *om_v, const l
 // Slab partials are combined with fp64 atomic adds (order-dependent in the last bits: statistics, not parity data).
 typedef double klhr_d4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(64) void klhr_gram_mfma_kernel(const double *X, long long nrows, int D, int Dp, long long rows_per_slab,
-                                                            double *G /* Dp x Dp, zero-initialised */) {
+                                                            const int *status, int C, double *G /* Dp x Dp, zero-initialised */) {
     const int lane = threadIdx.x & 63;
     const int tiles = Dp / 16;
     const int ti = blockIdx.x / tiles, tj = blockIdx.x % tiles;
@@ -1061,7 +1063,7 @@ __global__ __launch_bounds__(64) void klhr_gram_mfma_kernel(const double *X, lon
     for (long long r0 = r_begin; r0 < r_end; r0 += 4) {
         const long long r = r0 + kk;
         double a = 0.0, b = 0.0;
-        if (r < r_end) {
+        if (r < r_end && !(status[r % C] & 2)) {          // rows are [iteration][chain]; non-finite chains contribute nothing
             const double *row = X + r * (long long)D;
             a = ca < D ? row[ca] : (ca == D ? 1.0 : 0.0);
             b = cb < D ? row[cb] : (cb == D ? 1.0 : 0.0);

@@ -135,12 +135,13 @@ class ShardedKLHRSINH:
                 run(1, accumulate=False)              # the closure iteration (klhr_sinh.py:268-280)
                 left -= 1
                 self._gram = None
-                if tot[0] > 2:
+                if tot[0] > 2 and np.isfinite(tot).all():
                     s.pool_apply_full(*pooled_full(tot, D, s.ncol))
             else:
                 tot = allreduce_sum(s.pool_stats(), self.dist, self.local_rank)
                 run(1)                                # the closure iteration
                 left -= 1
-                mean, var = pooled_moments(tot)
-                s.pool_apply(mean, var)
+                if tot[0] > 2 and np.isfinite(tot).all():
+                    mean, var = pooled_moments(tot)
+                    s.pool_apply(mean, var)
         return np.concatenate(out) if record else None
