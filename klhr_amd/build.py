@@ -1,8 +1,15 @@
 """Build libklhr_hip.so for gfx950 in-tree (klhr_amd/lib/).  `python -m klhr_amd.build [--force] [-v]`
 
 Eight translation units are compiled in parallel and linked: klhr_api.hip (C ABI + small kernels) and klhr_hot.hip once
-per (sampler variant, over-relaxation) pair (six) plus once for the slice sampler — see the comment at the top of klhr_hot.hip."""
+per (sampler variant, over-relaxation) pair (six) plus once for the slice sampler — see the comment at the top of klhr_hot.hip.
+
+Every unit's device assembly is kept (-save-temps) and checked with tools/exec_lint.py: at 256 VGPR + ~250 AGPR the
+register allocator has been seen to place AGPR save copies ahead of a block's EXEC restore (they then save nothing and
+a chain's counters come back as garbage).  A flagged unit is rebuilt once with another allocation order
+(RETRY_FLAGS); if it is still flagged the build fails rather than ship the kernel."""
+import glob
 import os
+import shutil
 import subprocess
 import sys
 
@@ -13,6 +20,18 @@ OBJ = os.path.join(HERE, "lib", "obj")
 DEPS = ["klhr_api.hip", "klhr_hot.hip", "klhr_kernels.hpp", "klhr_lane_kernel.hpp", "device_opt.hpp", "device_models.hpp",
         "device_rng.hpp", "zig_tables.h", os.path.join("..", "..", "include", "klhr.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"] + os.environ.get("KLHR_EXTRA_FLAGS", "").split()
+RETRY_FLAGS = ["-mllvm", "-greedy-regclass-priority-trumps-globalness=1"]
+LINT = os.path.join(HERE, "..", "tools", "exec_lint.py")
+
+
+def _lint(objdir):
+    """Flagged blocks in the device assembly that -save-temps left in objdir (empty list = clean)."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(LINT)))
+    import exec_lint
+    out = []
+    for asm in glob.glob(os.path.join(objdir, "*amdgcn*.s")):
+        out += exec_lint.lint(asm)
+    return out
 
 
 def needs_build():
@@ -33,19 +52,42 @@ def build(force=False, verbose=False, extra=()):
         for o in (0, 1):
             jobs.append((f"hot_v{v}_o{o}.o", ["-c", os.path.join(SRC, "klhr_hot.hip"), f"-DKLHR_VARIANT={v}", f"-DKLHR_OVERRELAX={o}"]))
     jobs.append(("hot_v3_o0.o", ["-c", os.path.join(SRC, "klhr_hot.hip"), "-DKLHR_VARIANT=3", "-DKLHR_OVERRELAX=0"]))     # slice.py
-    procs = []
-    for name, args in jobs:
-        cmd = [hipcc] + flags + args + ["-o", os.path.join(OBJ, name)]
-        procs.append((name, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-    failed = False
-    for name, pr in procs:
+    def launch(name, args, extra_flags=()):
+        d = os.path.join(OBJ, name[:-2])
+        shutil.rmtree(d, ignore_errors=True)
+        os.makedirs(d)
+        cmd = [hipcc] + flags + list(extra_flags) + args + ["-save-temps=obj", "-o", os.path.join(d, name)]
+        return subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+
+    def finish(name, pr):
         out, _ = pr.communicate()
         if verbose or pr.returncode != 0:
             sys.stderr.write(out)
-        failed |= pr.returncode != 0
-    if failed:
-        raise RuntimeError("hipcc failed")
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + [os.path.join(OBJ, n) for n, _ in jobs])
+        if pr.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {name}")
+
+    procs = [(name, args, launch(name, args)) for name, args in jobs]
+    flagged = []
+    for name, args, pr in procs:
+        finish(name, pr)
+        bad = _lint(os.path.join(OBJ, name[:-2]))
+        if bad:
+            flagged.append((name, args, bad))
+    retry = [(name, args, bad, launch(name, args, RETRY_FLAGS)) for name, args, bad in flagged]
+    for name, args, bad, pr in retry:
+        sys.stderr.write(f"klhr_amd.build: {name}: {len(bad)} block(s) with vector code ahead of the EXEC restore "
+                         f"({bad[0][0]} {bad[0][1]}); rebuilding with {' '.join(RETRY_FLAGS)}\n")
+        finish(name, pr)
+        still = _lint(os.path.join(OBJ, name[:-2]))
+        if still:
+            raise RuntimeError(f"{name}: device code still fails tools/exec_lint.py after the retry: {still[:3]}")
+    keep_asm = bool(os.environ.get("KLHR_KEEP_ASM"))          # 10 MB per unit; kept only on request
+    for name, _ in jobs:          # drop the bulky -save-temps files
+        d = os.path.join(OBJ, name[:-2])
+        for f in os.listdir(d):
+            if not (f == name or (keep_asm and f.endswith("gfx950.s"))):
+                os.remove(os.path.join(d, f))
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + [os.path.join(OBJ, n[:-2], n) for n, _ in jobs])
     return OUT
 
 

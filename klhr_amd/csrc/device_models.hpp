@@ -188,6 +188,9 @@ __device__ __forceinline__ void model_eval(const ModelData &md, XR xr, double cl
 #ifndef KLHR_TR_BLK
 #define KLHR_TR_BLK 8
 #endif
+#ifndef KLHR_GLMM_BLK
+#define KLHR_GLMM_BLK 4          // years of glmm-poisson evaluated together (independent exp chains)
+#endif
 template <int B>
 __device__ __forceinline__ void tr_load_block(const double2 *TR, int i0, int D, double2 (&r)[B]) {
     if (i0 + B <= D) {          // whole block inside the row: immediate offsets, no index arithmetic
@@ -257,6 +260,55 @@ __device__ __forceinline__ void model_eval_tr(const ModelData &md, const double2
         gdot = gd;
         logp = -0.5 * acc;
         return;
+    } else if constexpr (MODEL == MODEL_GLMM_POISSON) {
+        // model_eval's arithmetic in model_eval's order; the years are taken KLHR_GLMM_BLK at a time so that their
+        // exp() calls (the long dependent chains of this target) overlap — the wavefront is alone on its SIMD — and
+        // the accumulations then run over the block in index order.
+        const int n = md.n;
+        const double *x1 = md.aux, *x2 = md.aux + n, *x3 = md.aux + 2 * n, *Cn = md.aux + 3 * n;
+        const double2 ea = TR[0], eb0 = TR[1], eb1 = TR[2], eb2 = TR[3], el = TR[4];
+        const double alpha = fma(t, ea.y, ea.x), b0 = fma(t, eb0.y, eb0.x), b1 = fma(t, eb1.y, eb1.x), b2 = fma(t, eb2.y, eb2.x);
+        const double ell = fma(t, el.y, el.x), sigma = exp(ell);
+        double lp = -alpha * alpha * (1.0 / 50.0);
+        lp -= b0 * b0 * (1.0 / 50.0); lp -= b1 * b1 * (1.0 / 50.0); lp -= b2 * b2 * (1.0 / 50.0);
+        lp -= 0.5 * ell * ell;
+        double sr = 0, s1 = 0, s2 = 0, s3 = 0, sre = 0, see = 0, lik = 0, gd = 0;
+        constexpr int U = KLHR_GLMM_BLK;
+        for (int i0 = 0; i0 < n; i0 += U) {
+            double2 e2[U];
+            double xa[U], xb[U], xc[U], cc[U], e[U], eta[U], mu[U];
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                const int i = i0 + k < n ? i0 + k : n - 1;
+                e2[k] = TR[5 + i]; xa[k] = x1[i]; xb[k] = x2[i]; xc[k] = x3[i]; cc[k] = Cn[i];
+            }
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                e[k] = fma(t, e2[k].y, e2[k].x);
+                eta[k] = alpha + xa[k] * b0 + xb[k] * b1 + xc[k] * b2 + sigma * e[k];
+                mu[k] = exp(eta[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                if (i0 + k < n) {
+                    const double r = cc[k] - mu[k];
+                    lik += cc[k] * eta[k] - mu[k];
+                    see += e[k] * e[k];
+                    sr += r; s1 += xa[k] * r; s2 += xb[k] * r; s3 += xc[k] * r;
+                    sre += r * e[k];
+                    const double ge = -e[k] + sigma * r;
+                    gd += clipc(ge, cl) * e2[k].y;
+                }
+            }
+        }
+        lp += -0.5 * see + lik;
+        const double g0 = -alpha * (1.0 / 25.0) + sr, g1 = -b0 * (1.0 / 25.0) + s1, g2 = -b1 * (1.0 / 25.0) + s2, g3 = -b2 * (1.0 / 25.0) + s3;
+        const double g4 = -ell + sigma * sre;
+        gd += clipc(g0, cl) * ea.y; gd += clipc(g1, cl) * eb0.y; gd += clipc(g2, cl) * eb1.y; gd += clipc(g3, cl) * eb2.y;
+        gd += clipc(g4, cl) * el.y;
+        gdot = gd;
+        logp = lp;
+        return;
     }
     model_eval<MODEL>(md, [&](int i, double &xi, double &ri) { double2 v = TR[i]; ri = v.y; xi = fma(t, v.y, v.x); }, cl, NoSink(), logp, gdot);
 }
@@ -310,17 +362,32 @@ __device__ __forceinline__ void model_eval_split(const ModelData &md, const doub
         const double alpha = fma(t, ea.y, ea.x), b0 = fma(t, eb0.y, eb0.x), b1 = fma(t, eb1.y, eb1.x), b2 = fma(t, eb2.y, eb2.x);
         const double ell = fma(t, el.y, el.x), sigma = exp(ell);
         double sr = 0, s1 = 0, s2 = 0, s3 = 0, sre = 0, see = 0, lik = 0, gd = 0;
-        for (int i = l8; i < n; i += 8) {
-            const double2 e2 = TR[5 + i];
-            double e = fma(t, e2.y, e2.x);
-            double eta = alpha + x1[i] * b0 + x2[i] * b1 + x3[i] * b2 + sigma * e;
-            double mu = exp(eta);
-            double r = Cn[i] - mu;
-            lik += Cn[i] * eta - mu;
-            see += e * e;
-            sr += r; s1 += x1[i] * r; s2 += x2[i] * r; s3 += x3[i] * r;
-            sre += r * e;
-            gd += clipc(-e + sigma * r, cl) * e2.y;
+        constexpr int U = KLHR_GLMM_BLK;
+        for (int i0 = l8; i0 < n; i0 += 8 * U) {       // this lane's years, U at a time (independent exp chains)
+            double2 e2[U];
+            double xa[U], xb[U], xc[U], cc[U], e[U], eta[U], mu[U];
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                const int i = i0 + 8 * k < n ? i0 + 8 * k : i0;
+                e2[k] = TR[5 + i]; xa[k] = x1[i]; xb[k] = x2[i]; xc[k] = x3[i]; cc[k] = Cn[i];
+            }
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                e[k] = fma(t, e2[k].y, e2[k].x);
+                eta[k] = alpha + xa[k] * b0 + xb[k] * b1 + xc[k] * b2 + sigma * e[k];
+                mu[k] = exp(eta[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                if (i0 + 8 * k < n) {
+                    const double r = cc[k] - mu[k];
+                    lik += cc[k] * eta[k] - mu[k];
+                    see += e[k] * e[k];
+                    sr += r; s1 += xa[k] * r; s2 += xb[k] * r; s3 += xc[k] * r;
+                    sre += r * e[k];
+                    gd += clipc(-e[k] + sigma * r, cl) * e2[k].y;
+                }
+            }
         }
         sr = sum8(sr); s1 = sum8(s1); s2 = sum8(s2); s3 = sum8(s3); sre = sum8(sre); see = sum8(see); lik = sum8(lik); gd = sum8(gd);
         double lp = -alpha * alpha * (1.0 / 50.0);

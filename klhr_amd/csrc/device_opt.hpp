@@ -29,6 +29,28 @@
 
 namespace klhr {
 
+// Separately rounded a+b, a*b, a-b, as NumPy's element-wise operations and SciPy's `xk + alpha * pk` produce them.
+// (HIP's __dadd_rn / __dmul_rn / __dsub_rn are plain operators that the compiler contracts into FMAs with their
+// neighbours; these carry no contract flag.  The host-compiled parity harness is built with -ffp-contract=off.)
+#ifndef KLHR_HOST_HARNESS
+__device__ __forceinline__ double add_rn(double a, double b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ double mul_rn(double a, double b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ double sub_rn(double a, double b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+#else
+static inline double add_rn(double a, double b) { return a + b; }
+static inline double mul_rn(double a, double b) { return a * b; }
+static inline double sub_rn(double a, double b) { return a - b; }
+#endif
+
 enum { PC_INIT = 0, PC_W1 = 1, PC_W2 = 2, PC_ZOOM = 3, PC_DONE = 4 };
 
 // line-search scratch, overlaid: DCSRCH state and wolfe2/zoom state are never live together
@@ -68,7 +90,7 @@ __device__ __forceinline__ double amax_abs4(const double *g) {
 __device__ __forceinline__ void opt_request(Opt &o, double a) {
     o.areq = a;
 #pragma unroll
-    for (int i = 0; i < 4; i++) o.xt[i] = __dadd_rn(o.xk[i], __dmul_rn(a, o.pk[i]));
+    for (int i = 0; i < 4; i++) o.xt[i] = add_rn(o.xk[i], mul_rn(a, o.pk[i]));
 }
 
 // _dcsrch.py:502-728
@@ -329,8 +351,8 @@ __device__ inline void opt_advance(Opt &o, double f, const double *g) {
         double sk[4], yk[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            sk[i] = __dmul_rn(alpha_k, o.pk[i]);
-            o.xk[i] = __dadd_rn(o.xk[i], sk[i]);
+            sk[i] = mul_rn(alpha_k, o.pk[i]);
+            o.xk[i] = add_rn(o.xk[i], sk[i]);
             yk[i] = g[i] - o.gfk[i];
             o.gfk[i] = g[i];
         }

@@ -66,7 +66,7 @@ __device__ __forceinline__ double rng_uniform(Pcg64 &g) { return pcg_next_double
 
 // Generator.uniform(low, high): low + (high - low) * next_double, unfused (slice.py:95,130)
 __device__ __forceinline__ double rng_uniform_range(Pcg64 &g, double low, double high) {
-    return __dadd_rn(low, __dmul_rn(high - low, pcg_next_double(g)));
+    return add_rn(low, mul_rn(high - low, pcg_next_double(g)));
 }
 
 // Generator.exponential(): NumPy's 256-layer ziggurat for the standard exponential (distributions.c:
@@ -78,10 +78,10 @@ __device__ inline double rng_std_exponential(Pcg64 &g) {
         ri >>= 3;
         const int idx = (int)(ri & 0xff);
         ri >>= 8;
-        const double x = __dmul_rn((double)ri, KLHR_ZIG_WE[idx]);
+        const double x = mul_rn((double)ri, KLHR_ZIG_WE[idx]);
         if (ri < KLHR_ZIG_KE[idx]) return x;            // ~98.9 % of draws
         if (idx == 0) return ZIG_EXP_R - log1p(-pcg_next_double(g));
-        if (__dadd_rn(__dmul_rn(KLHR_ZIG_FE[idx - 1] - KLHR_ZIG_FE[idx], pcg_next_double(g)), KLHR_ZIG_FE[idx]) < exp(-x)) return x;
+        if (add_rn(mul_rn(KLHR_ZIG_FE[idx - 1] - KLHR_ZIG_FE[idx], pcg_next_double(g)), KLHR_ZIG_FE[idx]) < exp(-x)) return x;
     }
 }
 

@@ -101,7 +101,7 @@ __device__ __forceinline__ void sa_unpack(const double *eta, double tol, double 
 __device__ inline double sa_T(double x, const double *eta, double tol, double sc, bool sub = false) {
     double m, s, d, e;
     sa_unpack(eta, tol, sc, m, s, d, e, sub);
-    return __dadd_rn(m, __dmul_rn(s, sinh(clipc((asinh(x) + e) / d, sc))));
+    return add_rn(m, mul_rn(s, sinh(clipc((asinh(x) + e) / d, sc))));
 }
 // klhr_sinh.py:126-129
 __device__ inline double sa_T_inv(double x, const double *eta, double tol, double sc, bool sub = false) {
@@ -194,7 +194,7 @@ template <bool OVERRELAX>
 __device__ inline double gauss_zp(Pcg64 &rng, const double *eta, int K, double sc) {
     const double m = eta[0], s = exp(clipc(eta[1], sc));
     if constexpr (!OVERRELAX) {
-        return __dadd_rn(m, __dmul_rn(s, rng_std_normal(rng)));          // rng.normal(loc=m, scale=s)
+        return add_rn(m, mul_rn(s, rng_std_normal(rng)));          // rng.normal(loc=m, scale=s)
     } else {
         const double u = ndtr_erfc((0.0 - m) / s);
         int r = 0;
@@ -751,7 +751,7 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
                 KLHR_WAVE_SYNC();
                 for (int i = l8; i < D; i += 8) {
                     double2 v = TR[i];
-                    v.x = __dadd_rn(__dmul_rn(v.y, x1), v.x);          // theta = rho * x1 + theta
+                    v.x = add_rn(mul_rn(v.y, x1), v.x);          // theta = rho * x1 + theta
                     TR[i] = v;
                 }
                 acc += (1.0 - acc) / (double)draw;
@@ -791,8 +791,8 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
             double d2 = 0.0;
             for (int i = l8; i < D; i += 8) {
                 double2 v = TR[i];
-                double thp = __dadd_rn(__dmul_rn(zp, v.y), v.x);
-                double nx = __dadd_rn(__dmul_rn(ad, thp), __dmul_rn(na, v.x));     // a*thetap + (1-a)*theta
+                double thp = add_rn(mul_rn(zp, v.y), v.x);
+                double nx = add_rn(mul_rn(ad, thp), mul_rn(na, v.x));     // a*thetap + (1-a)*theta
                 d2 += (nx - v.x) * (nx - v.x);
                 v.x = nx;
                 TR[i] = v;
@@ -839,7 +839,7 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
                         double mr[OCT_CH];
                         oct_load_chunk(p.mean + c * (long long)D, 1, l8, k0, D, mr);
 #pragma unroll
-                        for (int k = 0; k < OCT_CH; k++) { const int i = l8 + 8 * (k0 + k); if (i < D) Z[i] = __dsub_rn(TR[i].x, mr[k]); }
+                        for (int k = 0; k < OCT_CH; k++) { const int i = l8 + 8 * (k0 + k); if (i < D) Z[i] = sub_rn(TR[i].x, mr[k]); }
                     }
                 }
                 KLHR_WAVE_SYNC();
@@ -977,7 +977,7 @@ __global__ void klhr_mh_kernel(const KParams p, double stepsize, int seed_only) 
     for (int it = 0; it < (seed_only ? 0 : p.n_iters); ++it) {
         draw += 1;
         for (int i = 0; i < D; i++) pr[i] = rng_std_normal(rng);
-        for (int i = 0; i < D; i++) pr[i] = __dadd_rn(th[i], __dmul_rn(pr[i], stepsize));
+        for (int i = 0; i < D; i++) pr[i] = add_rn(th[i], mul_rn(pr[i], stepsize));
         double lpp, lpc, gd;
         model_eval<MODEL>(p.md, [&](int i, double &xi, double &ri) { xi = pr[i]; ri = 0.0; }, INFINITY, NoSink(), lpp, gd);
         model_eval<MODEL>(p.md, [&](int i, double &xi, double &ri) { xi = th[i]; ri = 0.0; }, INFINITY, NoSink(), lpc, gd);
@@ -992,7 +992,7 @@ __global__ void klhr_mh_kernel(const KParams p, double stepsize, int seed_only) 
         const double mn = (r != r) ? r : (r < 0 ? r : 0.0);
         const int a = logu < mn ? 1 : 0;
         const double ad = (double)a, na = (double)(1 - a);
-        for (int i = 0; i < D; i++) th[i] = __dadd_rn(__dmul_rn(ad, pr[i]), __dmul_rn(na, th[i]));
+        for (int i = 0; i < D; i++) th[i] = add_rn(mul_rn(ad, pr[i]), mul_rn(na, th[i]));
         acc += (ad - acc) / (double)draw;
         if (p.draws) {
             double *out = p.draws + ((long long)it * p.C + c) * D;

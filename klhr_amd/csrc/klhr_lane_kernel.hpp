@@ -279,9 +279,9 @@ __device__ __forceinline__ void lane_eval_kl(const KParams &p, const double2 *TR
     double P0[5], P1[5];
     lane_kl_group<MODEL, SUB, 4>(p, TR, xt[0], k, p.asx, p.wq, P0);
     lane_kl_group<MODEL, SUB, 4>(p, TR, xt[0], k, p.asx + 4, p.wq + 4, P1);
-    f = __dadd_rn(P0[0], P1[0]);
+    f = add_rn(P0[0], P1[0]);
 #pragma unroll
-    for (int j = 0; j < 4; j++) g[j] = __dadd_rn(P0[j + 1], P1[j + 1]);
+    for (int j = 0; j < 4; j++) g[j] = add_rn(P0[j + 1], P1[j + 1]);
 }
 
 // KLHR objective (klhr.py:109-124): 8 nodes y_n = s x_n + m, raw gradient — as node groups with the same fixed summation
@@ -319,9 +319,9 @@ __device__ __forceinline__ void lane_eval_kl_gauss(const KParams &p, const doubl
     double P0[5], P1[5];
     lane_gauss_group<MODEL, 4>(p, TR, xt[0], s_, p.xq, p.wq, P0);
     lane_gauss_group<MODEL, 4>(p, TR, xt[0], s_, p.xq + 4, p.wq + 4, P1);
-    f = -(__dadd_rn(P0[0], P1[0]) + xt[1]);
-    g[0] = -__dadd_rn(P0[1], P1[1]);
-    g[1] = -(__dadd_rn(P0[2], P1[2]) + 1.0);
+    f = -(add_rn(P0[0], P1[0]) + xt[1]);
+    g[0] = -add_rn(P0[1], P1[1]);
+    g[1] = -(add_rn(P0[2], P1[2]) + 1.0);
     g[2] = g[3] = 0.0;
 }
 
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
                                 if constexpr (GAUSS) lane_gauss_group<MODEL, 4>(p, TR, o.xt[0], sg, shx + LANE_Q + 4 * h, shx + LANE_Q + 8 + 4 * h, part);
                                 else lane_kl_group<MODEL, SUB, 4>(p, TR, o.xt[0], k, shx + LANE_Q + 4 * h, shx + LANE_Q + 8 + 4 * h, part);
 #pragma unroll
-                                for (int j = 0; j < 5; j++) acc5[j] = h == 0 ? part[j] : __dadd_rn(acc5[j], part[j]);
+                                for (int j = 0; j < 5; j++) acc5[j] = h == 0 ? part[j] : add_rn(acc5[j], part[j]);
                             }
                             if constexpr (GAUSS) { f = -(acc5[0] + o.xt[1]); g[0] = -acc5[1]; g[1] = -(acc5[2] + 1.0); g[2] = g[3] = 0.0; }
                             else { f = acc5[0]; g[0] = acc5[1]; g[1] = acc5[2]; g[2] = acc5[3]; g[3] = acc5[4]; }
@@ -500,8 +500,8 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
                             double r5[5];
 #pragma unroll
                             for (int j = 0; j < 5; j++)
-                                r5[j] = __dadd_rn(__dadd_rn(__dadd_rn(pp[j], pp[5 + j]), __dadd_rn(pp[10 + j], pp[15 + j])),
-                                                  __dadd_rn(__dadd_rn(pp[20 + j], pp[25 + j]), __dadd_rn(pp[30 + j], pp[35 + j])));
+                                r5[j] = add_rn(add_rn(add_rn(pp[j], pp[5 + j]), add_rn(pp[10 + j], pp[15 + j])),
+                                                  add_rn(add_rn(pp[20 + j], pp[25 + j]), add_rn(pp[30 + j], pp[35 + j])));
                             if constexpr (GAUSS) { f = -(r5[0] + o.xt[1]); g[0] = -r5[1]; g[1] = -(r5[2] + 1.0); g[2] = g[3] = 0.0; }
                             else { f = r5[0]; g[0] = r5[1]; g[1] = r5[2]; g[2] = r5[3]; g[3] = r5[4]; }
                         }
@@ -585,8 +585,8 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
             double d2 = 0.0;
             for (int i = 0; i < D; i++) {
                 double2 v = TR[i];
-                double thp = __dadd_rn(__dmul_rn(zp, v.y), v.x);
-                double nx = __dadd_rn(__dmul_rn(ad, thp), __dmul_rn(na, v.x));
+                double thp = add_rn(mul_rn(zp, v.y), v.x);
+                double nx = add_rn(mul_rn(ad, thp), mul_rn(na, v.x));
                 if (VARIANT == VAR_GAUSS) d2 += (nx - v.x) * (nx - v.x);
                 v.x = nx;
                 TR[i] = v;
@@ -627,7 +627,7 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
                     double mr[LANE_CH];
                     lane_load_chunk(p.mean + c * (long long)D, 1, i0, D, mr);
 #pragma unroll
-                    for (int k = 0; k < LANE_CH; k++) if (i0 + k < D) Z[i0 + k] = __dsub_rn(TR[i0 + k].x, mr[k]);
+                    for (int k = 0; k < LANE_CH; k++) if (i0 + k < D) Z[i0 + k] = sub_rn(TR[i0 + k].x, mr[k]);
                 }
                 pcan += 1;
                 lane_pca_update(p, c, pcan, Z);

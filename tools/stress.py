@@ -20,6 +20,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "one":
 models = ["funnel10", "funnel100", "illnormal100", "glmm45", "normal2", "earnings", "ar1x100"]
 bad = 0
 mode = sys.argv[1] if len(sys.argv) > 1 else "base"
+if len(sys.argv) > 2:                      # optional: restrict to one model, e.g. `stress.py base glmm45`
+    models = [m for m in models if m == sys.argv[2]]
 if mode == "flags":      # the flag matrix of write_experiments.py:25-27 at two chain counts
     cases = [(m, v, C, o, f) for m, v, C, o, f in itertools.product(models, (0, 1, 2, 3), (9, 200), (0, 1), (1, 2, 3)) if not (v == 3 and o)]
 else:
