@@ -103,6 +103,7 @@ def main():
     # ---- warmup (untimed): W iterations, which also closes the adaptation windows when W >= 100
     if args.warmup > 0:
         s.step(args.warmup)
+    s.reserve_draws(args.steps)     # the output buffer (np.zeros((M, D)) in experiment_funnel.py:48) exists before the clock starts
     s.sync()
     barrier()
     s.sync()

@@ -109,6 +109,9 @@ KLHR_API int klhr_window_closures(int64_t warmup, int64_t windowsize, int64_t wi
  * record_diag : also store per-chain diagnostics of the LAST iteration (rho, eta, counters).       */
 KLHR_API int klhr_step(klhr_sampler *s, int64_t n_iters, int record_draws, int record_diag);
 KLHR_API int klhr_get_draws(klhr_sampler *s, double *host_out, int64_t first_iter, int64_t n_iters); /* [n][C][D] */
+/* allocate the device buffer for n_iters recorded draws ahead of time (the counterpart of `thetas = np.zeros((M, D))`,
+ * experiment_funnel.py:48); without it the first recording klhr_step allocates it.                  */
+KLHR_API int klhr_reserve_draws(klhr_sampler *s, int64_t n_iters);
 
 /* pieces of draw(), for teacher-forced parity tests and for callers of the reference's methods:
  *   klhr_random_direction  <- KLHRSINH._random_direction()         klhr_sinh.py:203-213

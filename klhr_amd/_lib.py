@@ -60,6 +60,7 @@ def lib():
         "klhr_window_closures": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, i64p, C.c_int]),
         "klhr_step": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int]),
         "klhr_get_draws": (C.c_int, [vp, dp, C.c_int64, C.c_int64]),
+        "klhr_reserve_draws": (C.c_int, [vp, C.c_int64]),
         "klhr_random_direction": (C.c_int, [vp, dp]),
         "klhr_fit": (C.c_int, [vp, dp, dp]),
         "klhr_metropolis": (C.c_int, [vp, dp, dp]),
@@ -90,7 +91,7 @@ def lib():
 
 EXPORTS = ["klhr_create", "klhr_destroy", "klhr_last_error", "klhr_abi_version", "klhr_device_count", "klhr_dim", "klhr_chains", "klhr_sync",
            "klhr_kernel_variant",
-           "klhr_seed", "klhr_seed_state", "klhr_window_closures", "klhr_step", "klhr_get_draws", "klhr_random_direction",
+           "klhr_seed", "klhr_seed_state", "klhr_window_closures", "klhr_step", "klhr_get_draws", "klhr_reserve_draws", "klhr_random_direction",
            "klhr_fit", "klhr_metropolis", "klhr_adapt", "klhr_set_slice", "klhr_slice_step", "klhr_kl_eval", "klhr_line_eval", "klhr_log_density_gradient",
            "klhr_primitives", "klhr_get_state", "klhr_set_state", "klhr_mh_seed", "klhr_mh_step", "klhr_pool_stats",
            "klhr_pool_apply", "klhr_pool_gram", "klhr_pool_apply_full", "klhr_last_step_timing"]
@@ -183,6 +184,9 @@ class Sampler:
 
     def sync(self):
         self._ck(self._L.klhr_sync(self._h), "klhr_sync")
+
+    def reserve_draws(self, n):
+        self._ck(self._L.klhr_reserve_draws(self._h, int(n)), "klhr_reserve_draws")
 
     def kernel_name(self):
         return "klhr_lane_kernel" if self._L.klhr_kernel_variant(self._h) == 1 else "klhr_iter_kernel"

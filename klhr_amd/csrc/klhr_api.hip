@@ -335,6 +335,12 @@ static int ensure_draws(klhr_sampler *s, int64_t n_iters) {
     return 0;
 }
 
+extern "C" int klhr_reserve_draws(klhr_sampler *s, int64_t n_iters) {
+    if (!s) return KLHR_ERR_ARG;
+    if (n_iters < 0) { s->err = "klhr_reserve_draws: n_iters < 0"; return KLHR_ERR_ARG; }
+    return ensure_draws(s, n_iters);
+}
+
 static int run_phases(klhr_sampler *s, int phases, int64_t n_iters, int record_draws, int record_diag) {
     if (!s->seeded && (phases & (PH_DIR | PH_FIT | PH_MH))) { s->err = "klhr: chains are not seeded (call klhr_seed or set RNG/theta state)"; return KLHR_ERR_STATE; }
     HIPCHECK(s, hipSetDevice(s->cfg.device));

@@ -214,15 +214,15 @@ __device__ inline double gauss_zp(Pcg64 &rng, const double *eta, int K, double s
     }
 }
 // The over-relaxed proposals run once per iteration but, inlined, their loops and the Phi / Phi^-1 expansions sit in the
-// register allocation of the whole kernel (~1.4 KB of scratch per lane, -17 % throughput with overrelaxed=True).
-// Out-of-line by-value wrappers (-DKLHR_OR_NOINLINE) remove that cost, BUT one instantiation built that way
-// (klhr_iter_kernel<glmm-poisson, over-relaxed, SUBKLHRSINH>) faulted on the device in tools/stress.py — a function call
-// out of a 100 KB kernel that also spills is not something this toolchain gets right every time — so the default is the
-// inlined form and the out-of-line form stays an experiment.
-#ifdef KLHR_OR_NOINLINE
-#define KLHR_OR_ATTR __attribute__((noinline))
-#else
+// register allocation of the whole kernel (~1.4 KB of scratch per lane, -10 % throughput with overrelaxed=True).
+// They are therefore out-of-line by-value calls (-2 %).  An earlier build of that form faulted in
+// klhr_iter_kernel<glmm-poisson, over-relaxed, SUBKLHRSINH>; the cause was the misplaced AGPR copies that
+// tools/exec_lint.py now catches at build time (that instantiation is flagged and rebuilt by klhr_amd/build.py).
+// -DKLHR_OR_INLINE restores the inlined form.
+#ifdef KLHR_OR_INLINE
 #define KLHR_OR_ATTR __forceinline__
+#else
+#define KLHR_OR_ATTR __attribute__((noinline))
 #endif
 struct ZpOut { double zp; Pcg64 rng; };
 __device__ KLHR_OR_ATTR ZpOut overrelaxed_zp_call(Pcg64 rng, double e0, double e1, double e2, double e3, int K, double tol,
