@@ -392,7 +392,7 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
         if (active) {
             if (p.phases & PH_DIR) {
                 const double u_choice = (p.flags & FLAG_EIGEN_ONE) ? pcg_next_double(rng) : 0.0;
-                for (int k = 0; k < D; k++) Z[k] = rng_std_normal(rng);
+                for (int k = 0; k < D; k++) Z[k] = rng_std_normal_call(rng);
                 lane_direction(p, c, TR, Z, u_choice);
                 if (p.flags & FLAG_DIAG) {
                     double *rg = p.d_rho + c * (long long)D;
@@ -415,12 +415,12 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
             {
                 double x0v[4] = {0, 0, 0, 0};
                 if (active) {
-                    x0v[0] = rng_std_normal(rng) * p.initscale;
+                    x0v[0] = rng_std_normal_call(rng) * p.initscale;
                     if (VARIANT != VAR_GAUSS) {              // klhr.py's fit draws no further normals (klhr.py:134-139)
-                        (void)rng_std_normal(rng);
-                        (void)rng_std_normal(rng);
-                        fit_n2 = rng_std_normal(rng) * p.initscale;
-                        if (VARIANT == VAR_SINH) fit_n3 = rng_std_normal(rng) * p.initscale;     // size = 3 for SUBKLHRSINH
+                        (void)rng_std_normal_call(rng);
+                        (void)rng_std_normal_call(rng);
+                        fit_n2 = rng_std_normal_call(rng) * p.initscale;
+                        if (VARIANT == VAR_SINH) fit_n3 = rng_std_normal_call(rng) * p.initscale;     // size = 3 for SUBKLHRSINH
                     }
                 }
                 if (diag && active) dd[KLHR_D_X0] = x0v[0];
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
             if constexpr (VARIANT == VAR_GAUSS && OVERRELAX) { const ZpOut zo = gauss_overrelaxed_zp_call(rng, eta[0], eta[1], Kc, p.scale_clip); zp = zo.zp; rng = zo.rng; }
             else if constexpr (VARIANT == VAR_GAUSS) zp = gauss_zp<false>(rng, eta, Kc, p.scale_clip);
             else if constexpr (OVERRELAX) { const ZpOut zo = overrelaxed_zp_call(rng, eta[0], eta[1], eta[2], eta[3], p.K, p.tol, p.scale_clip, VARIANT == VAR_SUB); zp = zo.zp; rng = zo.rng; }
-            else zp = sa_T(rng_std_normal(rng), eta, p.tol, p.scale_clip, VARIANT == VAR_SUB);
+            else zp = sa_T(rng_std_normal_call(rng), eta, p.tol, p.scale_clip, VARIANT == VAR_SUB);
             double t2[2] = {zp, 0.0}, lp2[2], gd2[2];
             model_eval_nv<MODEL, 2>(p.md, TR, t2, INFINITY, lp2, gd2);
             double r = lp2[0];
