@@ -55,7 +55,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=200)   # one launch of the same length as the timed one (closes both adaptation windows)
     ap.add_argument("--chains", type=int, default=65536, help="chains per GPU")
     ap.add_argument("--model", default="funnel", choices=["funnel", "ill-normal", "glmm-poisson", "normal"])
     ap.add_argument("--dim", type=int, default=10, help="model dimension (funnel: 1 + number of alphas)")

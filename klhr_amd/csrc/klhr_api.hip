@@ -345,8 +345,17 @@ static int run_phases(klhr_sampler *s, int phases, int64_t n_iters, int record_d
     if (!s->seeded && (phases & (PH_DIR | PH_FIT | PH_MH))) { s->err = "klhr: chains are not seeded (call klhr_seed or set RNG/theta state)"; return KLHR_ERR_STATE; }
     HIPCHECK(s, hipSetDevice(s->cfg.device));
     if (record_draws) { int rc = ensure_draws(s, n_iters); if (rc) return rc; s->draws_iters = n_iters; }
-    // chunk the iterations so that a single launch stays short; chain state persists in HBM between launches
-    const int64_t chunk_max = 50;
+    // Chunk the iterations so that a single launch stays short (tens of milliseconds); chain state persists in HBM between
+    // launches.  With one wavefront per SIMD a launch lasts as long as its slowest wavefront, and the spread of the
+    // wavefronts' summed fit lengths shrinks like 1/sqrt(iterations), so small problems take more iterations per launch:
+    // 50 for C*D >= 2.6e6 doubles of state, up to 200 below (funnel-10 x 65 536: 200).  KLHR_CHUNK overrides.
+    int64_t chunk_max = 50;
+    {
+        const double cd = (double)s->C * (double)s->D;
+        if (cd > 0 && cd < 2621440.0) chunk_max = (int64_t)(50.0 * 2621440.0 / cd);
+        if (chunk_max > 200) chunk_max = 200;
+        if (const char *e = getenv("KLHR_CHUNK")) { const long v = atol(e); if (v > 0) chunk_max = v; }
+    }
     HIPCHECK(s, hipEventRecord(s->ev0, s->stream));
     int launches = 0;
     for (int64_t done = 0; done < n_iters; done += chunk_max) {
