@@ -262,6 +262,29 @@ def test_chunked_launches_equal_single_launch(oracle):
         assert np.array_equal(a.get(f), b.get(f)), f
 
 
+def test_iterations_per_launch_and_reserved_buffer_do_not_change_results(monkeypatch):
+    """KLHR_CHUNK (iterations per kernel launch) and klhr_reserve_draws only change how the work is issued: recorded
+    draws and final state are bit-identical for 7, 50 and the default number of iterations per launch."""
+    stem, data = model_spec("funnel10")
+    seeds = np.arange(24, dtype=np.uint64) + 300
+    out = []
+    for chunk in (None, "7", "50"):
+        if chunk is None:
+            monkeypatch.delenv("KLHR_CHUNK", raising=False)
+        else:
+            monkeypatch.setenv("KLHR_CHUNK", chunk)
+        s = make_sampler(stem, data, 24, warmup=100)
+        s.seed(seeds)
+        if chunk == "7":
+            s.reserve_draws(120)
+        s.step(120, record_draws=True)
+        out.append((s.draws(0, 120), s.get("theta"), s.get("rng"), s.get("cov"), s.timing()[1]))
+    assert out[0][4] == 1 and out[1][4] == 18 and out[2][4] == 3          # launches: 120 in one / ceil(120/7) / ceil(120/50)
+    for o in out[1:]:
+        for a, b in zip(o[:4], out[0][:4]):
+            assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("name,variant", [("funnel10", 0), ("earnings", 0), ("funnel10", 2), ("funnel10", 1)])
 def test_chain_results_do_not_depend_on_wavefront_company(oracle, name, variant):
     """A chain is a pure function of its seed and the configuration: its draws are bit-identical whether it runs alone,
