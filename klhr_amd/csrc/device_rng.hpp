@@ -65,7 +65,9 @@ __device__ inline double rng_std_normal(Pcg64 &g) { return rng_std_normal_body(g
 
 // Out-of-line by-value form for the lane-per-chain kernel: one copy of the ziggurat loop (tail + wedge branches) per
 // kernel instead of one per call site keeps those branches out of the register allocation around the seven call sites
-// (+4 % on funnel-10; the octet kernel, which draws D normals per lane and iteration, is 3-10 % faster inlined).
+// (+4 % on funnel-10; the octet kernel, which draws D normals per lane and iteration, is 3-10 % faster inlined and
+// uses this form only for the fit's x0 and the MH proposal: the exit blocks of those two inlined loops are where the
+// register allocator misplaced AGPR copies, see tools/exec_lint.py).
 struct NormOut { double z; Pcg64 g; };
 __device__ __attribute__((noinline)) NormOut rng_std_normal_ool(Pcg64 g) {
     NormOut o;

@@ -619,7 +619,7 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
         if (p.phases & PH_FIT) {
             Opt o;
             {
-                double x0v[4] = {rng_std_normal(rng) * p.initscale, 0, 0, 0};
+                double x0v[4] = {rng_std_normal_call(rng) * p.initscale, 0, 0, 0};
                 dg_x0 = x0v[0];
                 opt_begin(o, 1, x0v, 1e-5);
             }
@@ -767,7 +767,7 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
             if constexpr (VARIANT == VAR_GAUSS && OVERRELAX) { const ZpOut zo = gauss_overrelaxed_zp_call(rng, eta[0], eta[1], Kc, p.scale_clip); zp = zo.zp; rng = zo.rng; }
             else if constexpr (VARIANT == VAR_GAUSS) zp = gauss_zp<false>(rng, eta, Kc, p.scale_clip);
             else if constexpr (OVERRELAX) { const ZpOut zo = overrelaxed_zp_call(rng, eta[0], eta[1], eta[2], eta[3], p.K, p.tol, p.scale_clip, VARIANT == VAR_SUB); zp = zo.zp; rng = zo.rng; }
-            else zp = sa_T(rng_std_normal(rng), eta, p.tol, p.scale_clip, VARIANT == VAR_SUB);
+            else zp = sa_T(rng_std_normal_call(rng), eta, p.tol, p.scale_clip, VARIANT == VAR_SUB);
             double logp, gdot;
             const double t = (l8 == 0) ? zp : 0.0;
             model_eval<MODEL>(md, [&](int i, double &xi, double &ri) { double2 v = TR[i]; ri = v.y; xi = fma(t, v.y, v.x); },
