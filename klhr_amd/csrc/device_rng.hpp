@@ -81,6 +81,49 @@ __device__ __forceinline__ double rng_std_normal_call(Pcg64 &g) {
     return o.z;
 }
 
+// Direction draw of the octet kernel: D normals per iteration, one after the other (the stream is sequential).  The
+// two table look-ups of the fast path (98.8 % of the draws) come from LDS copies of WI / KI (4 KB per wavefront) instead of
+// the vector cache — a wavefront alone on its SIMD otherwise waits out two dependent global-load latencies per normal
+// (23 % of an iteration at D = 100).  A draw that fails the fast test continues out of line, from the global tables,
+// with exactly the steps of rng_std_normal_body: same values, same stream position.
+#define KLHR_ZTAB_DOUBLES 512
+__device__ __attribute__((noinline)) NormOut rng_std_normal_slow(Pcg64 g, int idx, uint64_t rabs, double x) {
+    const double ZIG_R = 3.6541528853610088, ZIG_INV_R = 0.27366123732975828;
+    NormOut o;
+    for (;;) {
+        if (idx == 0) {
+            for (;;) {
+                double xx = -ZIG_INV_R * log1p(-pcg_next_double(g));
+                double yy = -log1p(-pcg_next_double(g));
+                if (yy + yy > xx * xx) { o.z = ((rabs >> 8) & 1) ? -(ZIG_R + xx) : ZIG_R + xx; o.g = g; return o; }
+            }
+        } else if (((KLHR_ZIG_FI[idx - 1] - KLHR_ZIG_FI[idx]) * pcg_next_double(g) + KLHR_ZIG_FI[idx]) < exp(-0.5 * x * x)) {
+            o.z = x; o.g = g; return o;
+        }
+        uint64_t r = pcg_next64(g);
+        idx = (int)(r & 0xff);
+        r >>= 8;
+        const int sign = (int)(r & 1);
+        rabs = (r >> 1) & 0x000fffffffffffffULL;
+        x = (double)rabs * KLHR_ZIG_WI[idx];
+        if (sign) x = -x;
+        if (rabs < KLHR_ZIG_KI[idx]) { o.z = x; o.g = g; return o; }
+    }
+}
+__device__ __forceinline__ double rng_std_normal_tab(Pcg64 &g, const double *wi_l, const uint64_t *ki_l) {
+    uint64_t r = pcg_next64(g);
+    const int idx = (int)(r & 0xff);
+    r >>= 8;
+    const int sign = (int)(r & 1);
+    const uint64_t rabs = (r >> 1) & 0x000fffffffffffffULL;
+    double x = (double)rabs * wi_l[idx];
+    if (sign) x = -x;
+    if (rabs < ki_l[idx]) return x;
+    const NormOut o = rng_std_normal_slow(g, idx, rabs, x);
+    g = o.g;
+    return o.z;
+}
+
 // Generator.uniform() == 0.0 + (1.0 - 0.0) * next_double
 __device__ __forceinline__ double rng_uniform(Pcg64 &g) { return pcg_next_double(g); }
 

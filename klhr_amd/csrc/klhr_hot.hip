@@ -35,7 +35,8 @@ void KLHR_CAT(launch_hot_v, KLHR_VARIANT, _o, KLHR_OVERRELAX)(const KParams &kp,
         const dim3 grid((kp.C + 7) / 8), block(64);
         // chain rows + staged model data (klhr_iter_kernel: ill-normal D doubles, glmm-poisson 4n doubles)
         const size_t naux = model_id == KLHR_MODEL_GLMM_POISSON ? (size_t)4 * kp.md.n : (model_id == KLHR_MODEL_ILL_NORMAL ? (size_t)kp.D : 0);
-        const size_t lds = ((size_t)8 * kp.S + naux) * sizeof(double);
+        size_t lds = ((size_t)8 * kp.S + naux) * sizeof(double);
+        if (lds + KLHR_ZTAB_DOUBLES * sizeof(double) <= 64 * 1024) lds += KLHR_ZTAB_DOUBLES * sizeof(double);      // ziggurat WI / KI copies
         switch (model_id) {
         case KLHR_MODEL_FUNNEL: hipLaunchKernelGGL((klhr_iter_kernel<MODEL_FUNNEL, O, V>), grid, block, lds, stream, kp); break;
         case KLHR_MODEL_ILL_NORMAL: hipLaunchKernelGGL((klhr_iter_kernel<MODEL_ILL_NORMAL, O, V>), grid, block, lds, stream, kp); break;

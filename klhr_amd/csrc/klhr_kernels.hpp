@@ -555,14 +555,23 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
     // the log-density loops then read it next to (theta_i, rho_i) instead of going to the vector cache per element
     // (all 64 lanes copy, also those of octets beyond the last chain, which leave right after)
     ModelData md = p.md;
+    const double *zwi = nullptr;          // LDS copies of the ziggurat's WI / KI tables (direction draw), when they fit
+    const uint64_t *zki = nullptr;
     {
         const int naux = MODEL == MODEL_GLMM_POISSON ? 4 * p.md.n : (MODEL == MODEL_ILL_NORMAL ? D : 0);
         if (naux > 0) {
             double *aux_l = lds + (size_t)8 * p.S;
             for (int i = lane; i < naux; i += 64) aux_l[i] = p.md.aux[i];
             md.aux = aux_l;
-            KLHR_WAVE_SYNC();
         }
+        // (pays from D ~ 64 on: +5 % at D = 100; below that the copy costs more than the look-ups save)
+        if (D >= 64 && ((size_t)8 * p.S + naux + KLHR_ZTAB_DOUBLES) * sizeof(double) <= 64 * 1024) {      // LDS: same test as launch_hot (klhr_hot.hip)
+            double *w_l = lds + (size_t)8 * p.S + naux;
+            uint64_t *k_l = reinterpret_cast<uint64_t *>(w_l + 256);
+            for (int i = lane; i < 256; i += 64) { w_l[i] = KLHR_ZIG_WI[i]; k_l[i] = KLHR_ZIG_KI[i]; }
+            zwi = w_l; zki = k_l;
+        }
+        KLHR_WAVE_SYNC();
     }
     if (c >= p.C) return;
     double2 *TR = reinterpret_cast<double2 *>(lds + (size_t)grp * p.S);
@@ -597,9 +606,16 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
         if (p.phases & PH_DIR) {
             // eigen_method_one: rng.choice() consumes one uniform BEFORE the D normals (klhr_sinh.py:207,212)
             const double u_choice = (p.flags & FLAG_EIGEN_ONE) ? pcg_next_double(rng) : 0.0;
-            for (int k = 0; k < D; k++) {
-                double z = rng_std_normal(rng);
-                if ((k & 7) == l8) Z[k] = z;
+            if (zwi) {
+                for (int k = 0; k < D; k++) {
+                    double z = rng_std_normal_tab(rng, zwi, zki);
+                    if ((k & 7) == l8) Z[k] = z;
+                }
+            } else {
+                for (int k = 0; k < D; k++) {
+                    double z = rng_std_normal(rng);
+                    if ((k & 7) == l8) Z[k] = z;
+                }
             }
             KLHR_WAVE_SYNC();
             direction_from_normals(p, c, TR, Z, l8, u_choice);
