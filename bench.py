@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--dim", type=int, default=10, help="model dimension (funnel: 1 + number of alphas)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ess", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the short runs of the other BASELINE configurations")
     ap.add_argument("--seed", type=int, default=20261004)
     args = ap.parse_args()
 

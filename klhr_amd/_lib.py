@@ -189,7 +189,8 @@ class Sampler:
         self._ck(self._L.klhr_reserve_draws(self._h, int(n)), "klhr_reserve_draws")
 
     def kernel_name(self):
-        return "klhr_lane_kernel" if self._L.klhr_kernel_variant(self._h) == 1 else "klhr_iter_kernel"
+        return {0: "klhr_iter_kernel", 1: "klhr_lane_kernel", 2: "klhr_stream_kernel+klhr_fit1_kernel+klhr_fit2_kernel"}[
+            self._L.klhr_kernel_variant(self._h)]
 
     def draws(self, first=0, n=None, total=None):
         n = int(n)

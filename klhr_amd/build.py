@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libklhr_hip.so")
 OBJ = os.path.join(HERE, "lib", "obj")
-DEPS = ["klhr_api.hip", "klhr_hot.hip", "klhr_kernels.hpp", "klhr_lane_kernel.hpp", "device_opt.hpp", "device_models.hpp",
+DEPS = ["klhr_api.hip", "klhr_hot.hip", "klhr_split.hip", "klhr_split.hpp", "klhr_kernels.hpp", "klhr_lane_kernel.hpp", "device_opt.hpp", "device_models.hpp",
         "device_rng.hpp", "zig_tables.h", os.path.join("..", "..", "include", "klhr.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"] + os.environ.get("KLHR_EXTRA_FLAGS", "").split()
 RETRY_FLAGS = ["-mllvm", "-greedy-regclass-priority-trumps-globalness=1"]
@@ -25,11 +25,16 @@ LINT = os.path.join(HERE, "..", "tools", "exec_lint.py")
 
 
 def _lint(objdir):
-    """Flagged blocks in the device assembly that -save-temps left in objdir (empty list = clean)."""
+    """Flagged blocks in the device assembly that -save-temps left in objdir (empty list = clean).  Fails closed: a unit
+    whose device assembly cannot be found (toolchain naming change, flags that drop -save-temps) is an error, not "clean"."""
     sys.path.insert(0, os.path.dirname(os.path.abspath(LINT)))
     import exec_lint
     out = []
-    for asm in glob.glob(os.path.join(objdir, "*amdgcn*.s")):
+    files = glob.glob(os.path.join(objdir, "*amdgcn*.s"))
+    if not files:
+        raise RuntimeError(f"klhr_amd.build: no device assembly (*amdgcn*.s) found in {objdir}: the code-generation check "
+                           "cannot run (did -save-temps change its file naming?)")
+    for asm in files:
         out += exec_lint.lint(asm)
     return out
 
@@ -52,6 +57,8 @@ def build(force=False, verbose=False, extra=()):
         for o in (0, 1):
             jobs.append((f"hot_v{v}_o{o}.o", ["-c", os.path.join(SRC, "klhr_hot.hip"), f"-DKLHR_VARIANT={v}", f"-DKLHR_OVERRELAX={o}"]))
     jobs.append(("hot_v3_o0.o", ["-c", os.path.join(SRC, "klhr_hot.hip"), "-DKLHR_VARIANT=3", "-DKLHR_OVERRELAX=0"]))     # slice.py
+    for v in (0, 1, 2):           # split-phase pipeline (klhr_split.hpp), one unit per variant
+        jobs.append((f"split_v{v}.o", ["-c", os.path.join(SRC, "klhr_split.hip"), f"-DKLHR_VARIANT={v}"]))
     def launch(name, args, extra_flags=()):
         d = os.path.join(OBJ, name[:-2])
         shutil.rmtree(d, ignore_errors=True)

@@ -75,11 +75,12 @@ __device__ __forceinline__ double npsign(double x) { return x > 0 ? 1.0 : (x < 0
 __device__ __forceinline__ double npclip(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
 __device__ __forceinline__ bool finite_(double x) { return isfinite(x); }
 
-// np.amax(np.abs(g)) over 4 entries: NaN propagates
+// np.amax(np.abs(g)) over N entries: NaN propagates (N = 4 covers the zero-padded entries: |0| never raises the maximum)
+template <int N = 4>
 __device__ __forceinline__ double amax_abs4(const double *g) {
     double m = fabs(g[0]);
 #pragma unroll
-    for (int i = 1; i < 4; i++) {
+    for (int i = 1; i < N; i++) {
         double a = fabs(g[i]);
         if (!(m != m) && (a != a || a > m)) m = a;
     }
@@ -87,10 +88,11 @@ __device__ __forceinline__ double amax_abs4(const double *g) {
 }
 
 // xk + a*pk, unfused like NumPy's element-wise loops
+template <int N = 4>
 __device__ __forceinline__ void opt_request(Opt &o, double a) {
     o.areq = a;
 #pragma unroll
-    for (int i = 0; i < 4; i++) o.xt[i] = add_rn(o.xk[i], mul_rn(a, o.pk[i]));
+    for (int i = 0; i < N; i++) o.xt[i] = add_rn(o.xk[i], mul_rn(a, o.pk[i]));
 }
 
 // _dcsrch.py:502-728
@@ -236,7 +238,10 @@ __device__ __forceinline__ void opt_cache_store(Opt &o, double f, const double *
 
 // Consume the objective value f and gradient g at o.xt; leave either the next request in o.xt or pc == PC_DONE.
 // OUTLINE selects the out-of-line dcstep (octet kernel); the arithmetic is identical.
-template <bool OUTLINE = false>
+// N = number of live coordinates (the problem's dimension, as SciPy sees it).  The monolithic kernels run every problem
+// through N = 4 with zero padding (padded terms add exact zeros); the split pipeline's fit kernels (klhr_split.hpp)
+// instantiate N = 1 for the mode search and N = 2 / 3 / 4 for the KL fits: same values, a fraction of the instructions.
+template <bool OUTLINE = false, int N = 4>
 __device__ inline void opt_advance(Opt &o, double f, const double *g) {
     const double c1 = 1e-4, c2 = 0.9, stpmin = 1e-100, stpmax = 1e100, xtol = 1e-14;
     const double phi0 = o.old_fval;
@@ -245,13 +250,13 @@ __device__ inline void opt_advance(Opt &o, double f, const double *g) {
     double alpha_k = 0.0;
     double dphi = 0.0;
 #pragma unroll
-    for (int i = 0; i < 4; i++) dphi += g[i] * o.pk[i];
+    for (int i = 0; i < N; i++) dphi += g[i] * o.pk[i];
 
     if (o.pc == PC_INIT) {
         o.old_fval = f;
         double n2 = 0;
 #pragma unroll
-        for (int i = 0; i < 4; i++) { o.gfk[i] = g[i]; n2 += g[i] * g[i]; }
+        for (int i = 0; i < N; i++) { o.gfk[i] = g[i]; n2 += g[i] * g[i]; }
         o.old_old_fval = f + sqrt(n2) / 2;
         act = A_LOOPHEAD;
     } else if (o.pc == PC_W1) {
@@ -300,7 +305,7 @@ __device__ inline void opt_advance(Opt &o, double f, const double *g) {
                 o.ls[L_STX] = stx; o.ls[L_FX] = fx; o.ls[L_GX] = gx; o.ls[L_STY] = sty; o.ls[L_FY] = fy; o.ls[L_GY] = gy;
                 o.ls[L_STMIN] = stmin; o.ls[L_STMAX] = stmax;
                 if (!finite_(stp)) act = A_W2START;
-                else opt_request(o, stp);
+                else opt_request<N>(o, stp);
             }
         }
     } else if (o.pc == PC_W2) {
@@ -311,17 +316,17 @@ __device__ inline void opt_advance(Opt &o, double f, const double *g) {
         else if (f > phi0 + c1 * alpha1 * o.derphi0 || (f >= phi_a0 && o.i2 > 0)) {
             o.ls[Z_ALO] = alpha0; o.ls[Z_AHI] = alpha1; o.ls[Z_PHILO] = phi_a0; o.ls[Z_PHIHI] = f; o.ls[Z_DERPHILO] = o.ls[Z_DERPHI_A0];
             o.ls[Z_PHIREC] = phi0; o.ls[Z_AREC] = 0; o.it = 0; o.pc = PC_ZOOM;
-            opt_request(o, zoom_pick(o));
+            opt_request<N>(o, zoom_pick(o));
         } else if (fabs(dphi) <= -c2 * o.derphi0) { act = A_SUCCESS; alpha_k = alpha1; }
         else if (dphi >= 0) {
             o.ls[Z_ALO] = alpha1; o.ls[Z_AHI] = alpha0; o.ls[Z_PHILO] = f; o.ls[Z_PHIHI] = phi_a0; o.ls[Z_DERPHILO] = dphi;
             o.ls[Z_PHIREC] = phi0; o.ls[Z_AREC] = 0; o.it = 0; o.pc = PC_ZOOM;
-            opt_request(o, zoom_pick(o));
+            opt_request<N>(o, zoom_pick(o));
         } else {
             double alpha2 = pymin2(2 * alpha1, stpmax);
             o.ls[Z_ALPHA0] = alpha1; o.ls[Z_ALPHA1] = alpha2; o.ls[Z_PHI_A0] = f; o.ls[Z_DERPHI_A0] = dphi;
             o.i2 += 1;
-            opt_request(o, alpha2);
+            opt_request<N>(o, alpha2);
         }
     } else if (o.pc == PC_ZOOM) {
         const double a_j = o.areq;
@@ -339,7 +344,7 @@ __device__ inline void opt_advance(Opt &o, double f, const double *g) {
         if (act == A_NONE) {
             o.it += 1;
             if (o.it > 10) act = A_FAIL;
-            else opt_request(o, zoom_pick(o));
+            else opt_request<N>(o, zoom_pick(o));
         }
     }
 
@@ -350,24 +355,24 @@ __device__ inline void opt_advance(Opt &o, double f, const double *g) {
         o.old_fval = f;
         double sk[4], yk[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < N; i++) {
             sk[i] = mul_rn(alpha_k, o.pk[i]);
             o.xk[i] = add_rn(o.xk[i], sk[i]);
             yk[i] = g[i] - o.gfk[i];
             o.gfk[i] = g[i];
         }
         o.k += 1;
-        gnorm = amax_abs4(o.gfk);
+        gnorm = amax_abs4<N>(o.gfk);
         double s2 = 0;
 #pragma unroll
-        for (int i = 0; i < 4; i++) s2 += fabs(o.pk[i]) * fabs(o.pk[i]);
+        for (int i = 0; i < N; i++) s2 += fabs(o.pk[i]) * fabs(o.pk[i]);
         if (gnorm <= o.gtol) o.pc = PC_DONE;
         else if (alpha_k * sqrt(s2) <= 0.0) o.pc = PC_DONE;
         else if (!finite_(o.old_fval)) { o.status = 2; o.pc = PC_DONE; }
         else {
             double rhok_inv = 0;
 #pragma unroll
-            for (int i = 0; i < 4; i++) rhok_inv += yk[i] * sk[i];
+            for (int i = 0; i < N; i++) rhok_inv += yk[i] * sk[i];
             const double rhok = rhok_inv == 0.0 ? 1000.0 : 1.0 / rhok_inv;
 #ifdef KLHR_BFGS_RANK2
             // Hk+1 = (I - rho s y^T) Hk (I - rho y s^T) + rho s s^T expanded to its rank-two form
@@ -376,41 +381,41 @@ __device__ inline void opt_advance(Opt &o, double f, const double *g) {
             // used by the host-compiled parity harness — by rounding only: tests/test_host_opt.py)
             double wl[4], wr[4], rs[4], cs_[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < N; j++) {
                 double a = 0, b = 0;
 #pragma unroll
-                for (int m = 0; m < 4; m++) { a += yk[m] * o.H[m * 4 + j]; b += o.H[j * 4 + m] * yk[m]; }
+                for (int m = 0; m < N; m++) { a += yk[m] * o.H[m * 4 + j]; b += o.H[j * 4 + m] * yk[m]; }
                 wl[j] = a; wr[j] = b;
             }
             double yHy = 0;
 #pragma unroll
-            for (int m = 0; m < 4; m++) yHy += yk[m] * wr[m];
+            for (int m = 0; m < N; m++) yHy += yk[m] * wr[m];
             const double cc = rhok * (1.0 + rhok * yHy);
 #pragma unroll
-            for (int i = 0; i < 4; i++) { rs[i] = rhok * sk[i]; cs_[i] = cc * sk[i]; }
+            for (int i = 0; i < N; i++) { rs[i] = rhok * sk[i]; cs_[i] = cc * sk[i]; }
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+            for (int i = 0; i < N; i++)
 #pragma unroll
-                for (int j = 0; j < 4; j++)
+                for (int j = 0; j < N; j++)
                     o.H[i * 4 + j] = ((o.H[i * 4 + j] - rs[i] * wl[j]) - wr[i] * rs[j]) + cs_[i] * sk[j];
 #else
             double T1[16];
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+            for (int i = 0; i < N; i++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
+                for (int j = 0; j < N; j++) {
                     double s = 0;
 #pragma unroll
-                    for (int m = 0; m < 4; m++) s += o.H[i * 4 + m] * ((m == j ? 1.0 : 0.0) - yk[m] * sk[j] * rhok);
+                    for (int m = 0; m < N; m++) s += o.H[i * 4 + m] * ((m == j ? 1.0 : 0.0) - yk[m] * sk[j] * rhok);
                     T1[i * 4 + j] = s;
                 }
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+            for (int i = 0; i < N; i++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
+                for (int j = 0; j < N; j++) {
                     double s = 0;
 #pragma unroll
-                    for (int m = 0; m < 4; m++) s += ((i == m ? 1.0 : 0.0) - sk[i] * yk[m] * rhok) * T1[m * 4 + j];
+                    for (int m = 0; m < N; m++) s += ((i == m ? 1.0 : 0.0) - sk[i] * yk[m] * rhok) * T1[m * 4 + j];
                     o.H[i * 4 + j] = s + rhok * sk[i] * sk[j];
                 }
 #endif
@@ -422,18 +427,18 @@ __device__ inline void opt_advance(Opt &o, double f, const double *g) {
     }
 
     if (act == A_LOOPHEAD) {
-        gnorm = amax_abs4(o.gfk);
+        gnorm = amax_abs4<N>(o.gfk);
         if (gnorm > o.gtol && o.k < o.n * 200) {
             double d0 = 0;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
+            for (int i = 0; i < N; i++) {
                 double s = 0;
 #pragma unroll
-                for (int j = 0; j < 4; j++) s += o.H[i * 4 + j] * o.gfk[j];
+                for (int j = 0; j < N; j++) s += o.H[i * 4 + j] * o.gfk[j];
                 o.pk[i] = -s;
             }
 #pragma unroll
-            for (int i = 0; i < 4; i++) d0 += o.gfk[i] * o.pk[i];
+            for (int i = 0; i < N; i++) d0 += o.gfk[i] * o.pk[i];
             o.derphi0 = d0;
             // scalar_search_wolfe1 + DCSRCH START
             double alpha1;
@@ -451,7 +456,7 @@ __device__ inline void opt_advance(Opt &o, double f, const double *g) {
                 o.ls[L_STY] = 0.0; o.ls[L_FY] = o.old_fval; o.ls[L_GY] = d0;
                 o.ls[L_STMIN] = 0; o.ls[L_STMAX] = alpha1 + 4.0 * alpha1;
                 if (!finite_(alpha1)) act = A_W2START;
-                else { o.pc = PC_W1; opt_request(o, alpha1); }
+                else { o.pc = PC_W1; opt_request<N>(o, alpha1); }
             }
         } else {
             o.pc = PC_DONE;
@@ -468,12 +473,12 @@ __device__ inline void opt_advance(Opt &o, double f, const double *g) {
         alpha1 = pymin2(alpha1, stpmax);
         o.ls[Z_ALPHA0] = 0; o.ls[Z_ALPHA1] = alpha1; o.ls[Z_PHI_A0] = o.old_fval; o.ls[Z_DERPHI_A0] = o.derphi0;
         o.i2 = 0; o.pc = PC_W2;
-        opt_request(o, alpha1);
+        opt_request<N>(o, alpha1);
     }
 
     if (o.pc == PC_DONE && o.status == 0) {
         // final status (_optimize.py:1478-1487)
-        gnorm = amax_abs4(o.gfk);
+        gnorm = amax_abs4<N>(o.gfk);
         if (o.k >= o.n * 200) o.status = 1;
         else if (gnorm != gnorm || o.old_fval != o.old_fval || o.xk[0] != o.xk[0] || o.xk[1] != o.xk[1] ||
                  o.xk[2] != o.xk[2] || o.xk[3] != o.xk[3]) o.status = 3;

@@ -22,6 +22,10 @@ void launch_hot_v1_o1(const KParams &, int, bool, hipStream_t);
 void launch_hot_v2_o0(const KParams &, int, bool, hipStream_t);
 void launch_hot_v2_o1(const KParams &, int, bool, hipStream_t);
 void launch_hot_v3_o0(const KParams &, int, bool, hipStream_t);
+// split-phase pipeline (klhr_split.hip), one unit per variant: what = 0 stream, 1 mode search, 2 KL fit, 3 probe
+void launch_split_v0(const KParams &, int, int, bool, int, int, hipStream_t);
+void launch_split_v1(const KParams &, int, int, bool, int, int, hipStream_t);
+void launch_split_v2(const KParams &, int, int, bool, int, int, hipStream_t);
 }  // namespace klhr
 
 using namespace klhr;
@@ -32,6 +36,9 @@ struct klhr_sampler {
     klhr_config cfg{};
     int C = 0, D = 0, ncol = 0, S = 0, S_lane = 0, n_model = 0;
     bool use_lane = false;       // lane-per-chain kernel (small D) instead of the octet-per-chain kernel
+    bool split = false;          // split-phase pipeline (klhr_split.hpp): tiled state layout, three kernels per iteration
+    size_t Cp = 0;               // chains the [C][D...] arrays are allocated for (whole tiles in the tiled layout)
+    int tw = 64;                 // tile width of the tiled layout: chains per tile = lanes of a streaming wavefront in use
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing_pending = false;
@@ -131,7 +138,20 @@ extern "C" int klhr_device_count(void) {
 extern "C" const char *klhr_last_error(const klhr_sampler *s) { return s ? s->err.c_str() : g_create_err.c_str(); }
 extern "C" int klhr_dim(const klhr_sampler *s) { return s ? s->D : KLHR_ERR_ARG; }
 extern "C" int klhr_chains(const klhr_sampler *s) { return s ? s->C : KLHR_ERR_ARG; }
-extern "C" int klhr_kernel_variant(const klhr_sampler *s) { return s ? (s->use_lane ? 1 : 0) : KLHR_ERR_ARG; }
+extern "C" int klhr_kernel_variant(const klhr_sampler *s) { return s ? (s->split ? 2 : (s->use_lane ? 1 : 0)) : KLHR_ERR_ARG; }
+
+// ---- host <-> device copies of [C][W] state arrays: the host side is always chain-major (the NumPy layout); the device
+// side is tiled [tile][w][64 lanes] for handles of the split pipeline
+template <class T>
+static void host_to_tiled(const T *src, T *dst, size_t C, size_t W, size_t tw) {
+    for (size_t c = 0; c < C; c++)
+        for (size_t w = 0; w < W; w++) dst[((c / tw) * W + w) * tw + (c % tw)] = src[c * W + w];
+}
+template <class T>
+static void tiled_to_host(const T *src, T *dst, size_t C, size_t W, size_t tw) {
+    for (size_t c = 0; c < C; c++)
+        for (size_t w = 0; w < W; w++) dst[c * W + w] = src[((c / tw) * W + w) * tw + (c % tw)];
+}
 
 template <class T>
 static int dalloc(klhr_sampler *s, T **p, size_t n) {
@@ -144,14 +164,16 @@ static int dalloc(klhr_sampler *s, T **p, size_t n) {
 
 static int reset_state(klhr_sampler *s) {
     KParams &k = s->kp;
-    const size_t C = s->C, D = s->D, nc = s->ncol, J = s->cfg.J;
+    const size_t Cc = s->C, D = s->D, nc = s->ncol, J = s->cfg.J;
+    const size_t C = s->Cp;        // allocation size of the [C][D...] arrays (== chains, or whole tiles)
     std::vector<double> ones(C * (D > nc ? D : nc), 1.0);        // cov (C x D) and eigvals (C x ncol; ncol may exceed D)
     std::vector<int> ident(C * D);
     for (size_t c = 0; c < C; c++)
-        for (size_t i = 0; i < D; i++) ident[c * D + i] = (int)i;
+        for (size_t i = 0; i < D; i++) ident[s->split ? ((c / s->tw) * D + i) * s->tw + (c % s->tw) : c * D + i] = (int)i;
     HIPCHECK(s, hipMemcpyAsync(k.cov, ones.data(), C * D * 8, hipMemcpyHostToDevice, s->stream));
     HIPCHECK(s, hipMemcpyAsync(k.rank, ident.data(), C * D * 4, hipMemcpyHostToDevice, s->stream));
-    HIPCHECK(s, hipMemcpyAsync(k.eigvals, ones.data(), C * nc * 8, hipMemcpyHostToDevice, s->stream));
+    HIPCHECK(s, hipMemcpyAsync(k.eigvals, ones.data(), Cc * nc * 8, hipMemcpyHostToDevice, s->stream));
+    if (k.fitbuf) HIPCHECK(s, hipMemsetAsync(k.fitbuf, 0, (size_t)F_NFIELDS * C * 8, s->stream));
     HIPCHECK(s, hipMemsetAsync(k.theta, 0, C * D * 8, s->stream));
     HIPCHECK(s, hipMemsetAsync(k.mean, 0, C * D * 8, s->stream));
     HIPCHECK(s, hipMemsetAsync(k.eigvecs, 0, C * D * nc * 8, s->stream));
@@ -172,7 +194,7 @@ static int reset_state(klhr_sampler *s) {
     HIPCHECK(s, hipMemsetAsync(k.d_diag, 0, C * KLHR_NDIAG * 8, s->stream));
     {   // KLHR variant: Smoother(K) state per chain = [x = K, count = 0, K, moved = 0]
         std::vector<double> ks(C * 4, 0.0);
-        for (size_t c = 0; c < C; c++) { ks[c * 4 + 0] = (double)s->cfg.K; ks[c * 4 + 2] = (double)s->cfg.K; }
+        for (size_t c = 0; c < Cc; c++) { ks[c * 4 + 0] = (double)s->cfg.K; ks[c * 4 + 2] = (double)s->cfg.K; }
         HIPCHECK(s, hipMemcpyAsync(k.kstate, ks.data(), C * 4 * 8, hipMemcpyHostToDevice, s->stream));
     }
     HIPCHECK(s, hipStreamSynchronize(s->stream));
@@ -237,26 +259,59 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
     while (SL % 32 != 2) SL++;
     s->S_lane = SL;
     s->use_lane = (D <= 26) && (((size_t)64 * SL + 624) * 8 <= 64 * 1024);   // + LANE_LDS_EXTRA (klhr_lane_kernel.hpp)
+    // split-phase pipeline: line-separable targets, any variant but the slice sampler; one [D][64] LDS column block per tile
+    const bool split_ok = (cfg->model_id == KLHR_MODEL_FUNNEL || cfg->model_id == KLHR_MODEL_ILL_NORMAL || cfg->model_id == KLHR_MODEL_NORMAL) &&
+                          cfg->variant != 3 && ((size_t)D * 16 + 512) * 8 <= 64 * 1024;
+    // default: the lane-per-chain kernel while a chain's row fits its LDS share (D <= 26), the split pipeline above that for
+    // the separable targets, the octet kernel for everything else.  KLHR_KERNEL = octet | lane | mono | split overrides
+    // (mono: the monolithic kernel the dimension selects; split: the split pipeline wherever it is supported) — used by
+    // the parity tests, which run every supported mapping.
+    s->split = split_ok && !s->use_lane;
     if (cfg->variant == 3) s->use_lane = false;          // the slice sampler runs on the octet kernel only
     else
     if (const char *kk = getenv("KLHR_KERNEL")) {
-        if (!strcmp(kk, "octet")) s->use_lane = false;
-        else if (!strcmp(kk, "lane") && ((size_t)64 * SL + 624) * 8 <= 64 * 1024) s->use_lane = true;
+        if (!strcmp(kk, "octet")) { s->use_lane = false; s->split = false; }
+        else if (!strcmp(kk, "lane")) { s->split = false; if (((size_t)64 * SL + 624) * 8 <= 64 * 1024) s->use_lane = true; }
+        else if (!strcmp(kk, "mono")) s->split = false;
+        else if (!strcmp(kk, "split")) s->split = split_ok;
     }
+    if (s->split) s->use_lane = false;
+    if (s->split) {
+        // Tile width of the streaming kernel: 64 lanes per tile use the whole wavefront, narrower tiles put more wavefronts —
+        // more loads in flight — on the machine.  The kernel is bound by memory latency, so: at least ~2 wavefronts per SIMD
+        // (2048 tiles) and at most ~24 KB of LDS column scratch per tile, down to 16 chains per tile.
+        int tw = 64;
+        while (tw > 16 && ((s->C + tw - 1) / tw < 2048 || (size_t)D * tw * 8 > 24 * 1024)) tw /= 2;
+        if (const char *e = getenv("KLHR_TILE")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) tw = v; }
+        s->tw = tw;
+    }
+    s->Cp = s->split ? ((size_t)s->C + s->tw - 1) / s->tw * s->tw : (size_t)s->C;
     auto bail = [&](int rc) { g_create_err = s->err; klhr_destroy(s); return rc; };
     {
         hipError_t e = hipSetDevice(cfg->device);
         if (e != hipSuccess) { s->err = std::string("hipSetDevice failed: ") + hipGetErrorString(e); return bail(KLHR_ERR_HIP); }
     }
-    if ((size_t)8 * S * 8 > 64 * 1024) { s->err = "klhr_create: model dimension too large for the LDS layout (D <= 1300)"; return bail(KLHR_ERR_ARG); }
+    {
+        // octet kernel: 8 chain rows of S doubles + the staged model data (ill-normal D, glmm-poisson 4n doubles) in 64 KB
+        const size_t naux = cfg->model_id == KLHR_MODEL_GLMM_POISSON ? (size_t)4 * n : (cfg->model_id == KLHR_MODEL_ILL_NORMAL ? (size_t)D : 0);
+        if (!s->split && ((size_t)8 * S + naux) * 8 > 64 * 1024) {
+            s->err = "klhr_create: model dimension too large for the LDS layout of the octet kernel (8 rows of 3 D doubles + staged model data "
+                     "must fit 64 KB: D <= ~340; ill-normal D <= ~320, glmm-poisson n <= ~290)";
+            return bail(KLHR_ERR_ARG);
+        }
+    }
 #define TRY(x) do { int _rc = (x); if (_rc) return bail(_rc); } while (0)
     auto hip_try = [&](hipError_t e, const char *what) { if (e != hipSuccess) { s->err = std::string(what) + ": " + hipGetErrorString(e); return (int)KLHR_ERR_HIP; } return 0; };
     TRY(hip_try(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking), "hipStreamCreate"));
     TRY(hip_try(hipEventCreate(&s->ev0), "hipEventCreate"));
     TRY(hip_try(hipEventCreate(&s->ev1), "hipEventCreate"));
     KParams &k = s->kp;
-    const size_t C = s->C, nc = s->ncol, J = cfg->J;
+    const size_t C = s->Cp, nc = s->ncol, J = cfg->J;
     k.C = s->C; k.D = D; k.S = S; k.ncol = s->ncol; k.J = cfg->J;
+    k.tiled = s->split ? 1 : 0; k.tw = s->tw; k.Cpad = (long long)s->Cp; k.draw_slot = 0;
+    if (s->split) { TRY(dalloc(s, &k.fitbuf, (size_t)F_NFIELDS * C)); TRY(dalloc(s, &k.qhead, 2 * 64 * 32)); }
+    k.fit_waves = 1024;          // 256 CUs x 4 SIMDs, one fit wavefront each (KLHR_FIT_WAVES overrides: tuning aid)
+    if (const char *e = getenv("KLHR_FIT_WAVES")) k.fit_waves = atoi(e);
     k.flags = (cfg->scale_dir_cov ? FLAG_SCALE_DIR_COV : 0) | (cfg->eigen_method_one ? FLAG_EIGEN_ONE : 0) |
               (cfg->overrelaxed ? FLAG_OVERRELAXED : 0);
     k.K = cfg->K;
@@ -325,6 +380,13 @@ static int launch_iter(klhr_sampler *s, const KParams &kp_in) {
     return 0;
 }
 
+static void launch_split(klhr_sampler *s, const KParams &kp, int what, int do_tail, int do_head) {
+    const bool o = s->cfg.overrelaxed != 0;
+    if (s->cfg.variant == 2) launch_split_v2(kp, s->cfg.model_id, what, o, do_tail, do_head, s->stream);
+    else if (s->cfg.variant == 1) launch_split_v1(kp, s->cfg.model_id, what, o, do_tail, do_head, s->stream);
+    else launch_split_v0(kp, s->cfg.model_id, what, o, do_tail, do_head, s->stream);
+}
+
 static int ensure_draws(klhr_sampler *s, int64_t n_iters) {
     size_t need = (size_t)n_iters * s->C * s->D * 8;
     if (need > s->draws_cap) {
@@ -345,6 +407,34 @@ static int run_phases(klhr_sampler *s, int phases, int64_t n_iters, int record_d
     if (!s->seeded && (phases & (PH_DIR | PH_FIT | PH_MH))) { s->err = "klhr: chains are not seeded (call klhr_seed or set RNG/theta state)"; return KLHR_ERR_STATE; }
     HIPCHECK(s, hipSetDevice(s->cfg.device));
     if (record_draws) { int rc = ensure_draws(s, n_iters); if (rc) return rc; s->draws_iters = n_iters; }
+    if (s->split) {
+        // Split-phase pipeline (klhr_split.hpp).  Iteration k = [stream kernel: tail of k-1 (MH, adaptation, draw output) +
+        // head of k (direction, line sums, the fit's normals)] -> mode-search kernel -> KL-fit kernel; one last stream launch
+        // runs the tail of the final iteration.  Everything is enqueued on the handle's stream without host synchronisation.
+        const int tailp = phases & (PH_MH | PH_ADAPT | PH_FIT), headp = phases & (PH_DIR | PH_FIT | PH_MH | PH_KL | PH_LINE);      // (a tail after a fit also books its evaluation counts)
+        HIPCHECK(s, hipEventRecord(s->ev0, s->stream));
+        for (int64_t it = 0; it <= n_iters; it++) {
+            KParams kp = s->kp;
+            kp.phases = phases;
+            kp.n_iters = 1;
+            if (record_diag) kp.flags |= FLAG_DIAG;
+            const int do_tail = it > 0 && tailp, do_head = it < n_iters && headp;
+            kp.draws = (record_draws && do_tail) ? s->d_draws : nullptr;
+            kp.draw_slot = (int)(it - 1);
+            if (do_tail || do_head) launch_split(s, kp, 0, do_tail, do_head);
+            if (it < n_iters && (phases & PH_FIT)) { launch_split(s, kp, 1, 0, 0); launch_split(s, kp, 2, 0, 0); }
+            if (it < n_iters && (phases & (PH_KL | PH_LINE))) {
+                const char *rep = getenv("KLHR_PROBE_REPEAT");
+                kp.n_iters = rep ? atoi(rep) : 1;
+                launch_split(s, kp, 3, 0, 0);
+            }
+            HIPCHECK(s, hipGetLastError());
+        }
+        HIPCHECK(s, hipEventRecord(s->ev1, s->stream));
+        s->timing_pending = true;
+        s->last_launches = (int)n_iters;
+        return KLHR_OK;
+    }
     // Chunk the iterations so that a single launch stays short (tens of milliseconds); chain state persists in HBM between
     // launches.  With one wavefront per SIMD a launch lasts as long as its slowest wavefront, and the spread of the
     // wavefronts' summed fit lengths shrinks like 1/sqrt(iterations), so small problems take more iterations per launch:
@@ -463,16 +553,32 @@ static int d2h(klhr_sampler *s, void *dst, const void *src, size_t bytes) {
     return 0;
 }
 
+// [C][W] arrays of doubles crossing the ABI: chain-major on the host, tiled on the device for split-pipeline handles
+static int up_cw(klhr_sampler *s, double *dst, const double *src, size_t W) {
+    if (!s->split) return h2d(s, dst, src, (size_t)s->C * W * 8);
+    std::vector<double> t(s->Cp * W, 0.0);
+    host_to_tiled(src, t.data(), (size_t)s->C, W, (size_t)s->tw);
+    return h2d(s, dst, t.data(), t.size() * 8);
+}
+static int down_cw(klhr_sampler *s, double *dst, const double *src, size_t W) {
+    if (!s->split) return d2h(s, dst, src, (size_t)s->C * W * 8);
+    std::vector<double> t(s->Cp * W);
+    int rc = d2h(s, t.data(), src, t.size() * 8);
+    if (rc) return rc;
+    tiled_to_host(t.data(), dst, (size_t)s->C, W, (size_t)s->tw);
+    return 0;
+}
+
 extern "C" int klhr_random_direction(klhr_sampler *s, double *rho_out) {
     if (!s) return KLHR_ERR_ARG;
     int rc = run_phases(s, PH_DIR, 1, 0, 1);
     if (rc) return rc;
-    return rho_out ? d2h(s, rho_out, s->kp.d_rho, (size_t)s->C * s->D * 8) : klhr_sync(s);
+    return rho_out ? down_cw(s, rho_out, s->kp.d_rho, (size_t)s->D) : klhr_sync(s);
 }
 
 extern "C" int klhr_fit(klhr_sampler *s, const double *rho, double *eta_out) {
     if (!s || !rho) return KLHR_ERR_ARG;
-    int rc = h2d(s, s->kp.d_rho, rho, (size_t)s->C * s->D * 8);
+    int rc = up_cw(s, s->kp.d_rho, rho, (size_t)s->D);
     if (rc) return rc;
     rc = run_phases(s, PH_FIT, 1, 0, 1);
     if (rc) return rc;
@@ -481,7 +587,7 @@ extern "C" int klhr_fit(klhr_sampler *s, const double *rho, double *eta_out) {
 
 extern "C" int klhr_metropolis(klhr_sampler *s, const double *eta, const double *rho) {
     if (!s || !eta || !rho) return KLHR_ERR_ARG;
-    int rc = h2d(s, s->kp.d_rho, rho, (size_t)s->C * s->D * 8);
+    int rc = up_cw(s, s->kp.d_rho, rho, (size_t)s->D);
     if (rc) return rc;
     rc = h2d(s, s->kp.d_eta, eta, (size_t)s->C * 4 * 8);
     if (rc) return rc;
@@ -501,7 +607,7 @@ extern "C" int klhr_set_slice(klhr_sampler *s, double w, double lower, double up
 extern "C" int klhr_slice_step(klhr_sampler *s, const double *rho) {
     if (!s || !rho) return KLHR_ERR_ARG;
     if (s->cfg.variant != 3) { s->err = "klhr_slice_step: handle was not created with variant 3 (Slice)"; return KLHR_ERR_STATE; }
-    int rc = h2d(s, s->kp.d_rho, rho, (size_t)s->C * s->D * 8);
+    int rc = up_cw(s, s->kp.d_rho, rho, (size_t)s->D);
     if (rc) return rc;
     rc = run_phases(s, PH_MH, 1, 0, 1);
     if (rc) return rc;
@@ -520,7 +626,7 @@ static int probe(klhr_sampler *s, int phase, const double *eta_or_t, int eta_col
     std::vector<double> e4(C * 4, 0.0);
     for (size_t c = 0; c < C; c++)
         for (int k = 0; k < eta_cols; k++) e4[c * 4 + k] = eta_or_t[c * eta_cols + k];
-    int rc = h2d(s, s->kp.d_rho, rho, C * s->D * 8);
+    int rc = up_cw(s, s->kp.d_rho, rho, (size_t)s->D);
     if (rc) return rc;
     rc = h2d(s, s->kp.d_eta, e4.data(), C * 4 * 8);
     if (rc) return rc;
@@ -624,10 +730,24 @@ static bool field_info(klhr_sampler *s, int field, void **ptr, size_t *bytes) {
     return false;
 }
 
+// width W of a tiled [C][W] field (0: the field is chain-major / per-chain scalars in either layout)
+static size_t tiled_width(klhr_sampler *s, int field) {
+    if (!s->split) return 0;
+    const size_t D = s->D;
+    switch (field) {
+    case KLHR_F_THETA: case KLHR_F_MEAN: case KLHR_F_COV: case KLHR_F_OM_M: case KLHR_F_OM_V: case KLHR_F_OMD_M: case KLHR_F_OMD_V:
+    case KLHR_F_RHO: return D;
+    case KLHR_F_EIGVECS: return D * s->ncol;
+    case KLHR_F_PCA_V: return D * s->cfg.J;
+    }
+    return 0;
+}
+
 extern "C" int klhr_get_state(klhr_sampler *s, int field, void *host_out, size_t bytes) {
     if (!s || !host_out) return KLHR_ERR_ARG;
     void *p; size_t nb;
     if (!field_info(s, field, &p, &nb) || nb != bytes) { s->err = "klhr_get_state: unknown field or size mismatch"; return KLHR_ERR_ARG; }
+    if (const size_t W = tiled_width(s, field)) return down_cw(s, (double *)host_out, (const double *)p, W);
     return d2h(s, host_out, p, nb);
 }
 
@@ -635,11 +755,13 @@ extern "C" int klhr_set_state(klhr_sampler *s, int field, const void *host_in, s
     if (!s || !host_in) return KLHR_ERR_ARG;
     void *p; size_t nb;
     if (!field_info(s, field, &p, &nb) || nb != bytes) { s->err = "klhr_set_state: unknown field or size mismatch"; return KLHR_ERR_ARG; }
-    int rc = h2d(s, p, host_in, nb);
+    int rc;
+    if (const size_t W = tiled_width(s, field)) rc = up_cw(s, (double *)p, (const double *)host_in, W);
+    else rc = h2d(s, p, host_in, nb);
     if (rc) return rc;
     if (field == KLHR_F_COV) {
         const int bs = 64;
-        hipLaunchKernelGGL(klhr_rank_kernel, dim3((s->C + bs - 1) / bs), dim3(bs), 0, s->stream, s->kp.cov, s->kp.rank, s->C, s->D);
+        hipLaunchKernelGGL(klhr_rank_kernel, dim3((s->C + bs - 1) / bs), dim3(bs), 0, s->stream, s->kp);
         HIPCHECK(s, hipGetLastError());
         HIPCHECK(s, hipStreamSynchronize(s->stream));
     }
@@ -695,7 +817,7 @@ extern "C" int klhr_pool_stats(klhr_sampler *s, double *out, size_t n_out) {
     HIPCHECK(s, hipSetDevice(s->cfg.device));
     double *d_o = nullptr;
     HIPCHECK(s, hipMalloc((void **)&d_o, n_out * 8));
-    hipLaunchKernelGGL(klhr_pool_kernel, dim3(s->D), dim3(256), 0, s->stream, s->kp.om_m, s->kp.om_v, s->kp.counters, s->kp.status, s->C, s->D, d_o);
+    hipLaunchKernelGGL(klhr_pool_kernel, dim3(s->D), dim3(256), 0, s->stream, s->kp, d_o);
     int rc = 0;
     { hipError_t e = hipGetLastError(); if (e != hipSuccess) { s->err = hipGetErrorString(e); rc = KLHR_ERR_HIP; } }
     if (!rc) rc = d2h(s, out, d_o, n_out * 8);
@@ -713,7 +835,7 @@ extern "C" int klhr_pool_apply(klhr_sampler *s, const double *mean, const double
     if (!rc) rc = h2d(s, d_m + D, cov, D * 8);
     if (!rc) {
         const int bs = 64;
-        hipLaunchKernelGGL(klhr_pool_apply_kernel, dim3((s->C + bs - 1) / bs), dim3(bs), 0, s->stream, d_m, d_m + D, s->kp.mean, s->kp.cov, s->kp.rank, s->C, s->D);
+        hipLaunchKernelGGL(klhr_pool_apply_kernel, dim3((s->C + bs - 1) / bs), dim3(bs), 0, s->stream, s->kp, d_m, d_m + D);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { s->err = hipGetErrorString(e); rc = KLHR_ERR_HIP; }
     }
@@ -773,8 +895,8 @@ extern "C" int klhr_pool_apply_full(klhr_sampler *s, const double *mean, const d
     if (!rc) rc = h2d(s, d_m + 2 * D + D * nc, eigvals, nc * 8);
     if (!rc) {
         const int bs = 64;
-        hipLaunchKernelGGL(klhr_pool_apply_full_kernel, dim3((s->C + bs - 1) / bs), dim3(bs), 0, s->stream, d_m, d_m + D, d_m + 2 * D,
-                           d_m + 2 * D + D * nc, s->kp.mean, s->kp.cov, s->kp.eigvecs, s->kp.eigvals, s->kp.rank, s->C, s->D, s->ncol);
+        hipLaunchKernelGGL(klhr_pool_apply_full_kernel, dim3((s->C + bs - 1) / bs), dim3(bs), 0, s->stream, s->kp, d_m, d_m + D, d_m + 2 * D,
+                           d_m + 2 * D + D * nc);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { s->err = hipGetErrorString(e); rc = KLHR_ERR_HIP; }
     }

@@ -63,7 +63,24 @@ struct KParams {
     long long warmup, windowsize;
     int nclos;
     const long long *closures;   // device array of window-closure draw indices
+    // split-phase pipeline (klhr_split.hpp): tiled = 1 -> every [C][D...] state array is stored [tile][coordinate][64 lanes]
+    int tiled, tw, draw_slot;    // tw: tile width (chains per tile: 16, 32 or 64)
+    long long Cpad;              // chains rounded up to whole tiles of 64
+    double *fitbuf;              // per-chain fit records, SoA [F_NFIELDS][Cpad]
+    unsigned int *qhead;         // [2][KLHR_NQ] heads of the fit sub-queues, one per 128-byte line
+    int fit_waves;               // wavefronts of a fit launch (0: one per 64 chains)
 };
+
+// per-chain fit record of the split pipeline, SoA: field f of chain c at fitbuf[f * Cpad + c]
+enum { F_S0 = 0, F_S1, F_S2, F_S3, F_S4, F_S5, F_S6, F_NN, F_X0, F_N2, F_N3, F_MODE, F_INIT1, F_PASS, F_NFEV1, F_NFEV2, F_NFIELDS };
+
+// index of coordinate i (and column j of ncol) of chain c in a [C][D] / [C][D][ncol] state array, either layout
+__device__ __forceinline__ long long kix(const KParams &p, long long c, int i) {
+    return p.tiled ? ((c / p.tw) * (long long)p.D + i) * p.tw + (c % p.tw) : c * (long long)p.D + i;
+}
+__device__ __forceinline__ long long kix2(const KParams &p, long long c, int i, int j, int ncol) {
+    return p.tiled ? ((c / p.tw) * (long long)p.D * ncol + (long long)i * ncol + j) * p.tw + (c % p.tw) : (c * (long long)p.D + i) * ncol + j;
+}
 
 // 8-lane all-reduce with DPP cross-lane moves (no LDS traffic): xor 1 and xor 2 inside each quad (quad_perm), then the
 // mirrored lane of the other quad (row_half_mirror).  Every step adds two values in commutative order, so all 8 lanes
@@ -912,15 +929,15 @@ __global__ void klhr_init_kernel(const KParams p, int theta_given, int max_tries
     const int D = p.D;
     Pcg64 rng;
     rng.sh = p.rng[c * 4 + 0]; rng.sl = p.rng[c * 4 + 1]; rng.ih = p.rng[c * 4 + 2]; rng.il = p.rng[c * 4 + 3];
-    double *th = p.theta + c * (long long)D;
+    double *th = p.theta;
     if (!theta_given)
         for (int i = 0; i < D; i++) (void)rng_std_normal(rng);     // rng.normal(scale=0.1, size=D), overwritten below
     int tries = 0, st = 0;
     for (;;) {
         tries++;
-        for (int i = 0; i < D; i++) th[i] = rng_std_normal(rng) * p.initscale;
+        for (int i = 0; i < D; i++) th[kix(p, c, i)] = rng_std_normal(rng) * p.initscale;
         double lp, gd, n2 = 0;
-        model_eval<MODEL>(p.md, [&](int i, double &xi, double &ri) { xi = th[i]; ri = 0.0; }, INFINITY,
+        model_eval<MODEL>(p.md, [&](int i, double &xi, double &ri) { xi = th[kix(p, c, i)]; ri = 0.0; }, INFINITY,
                           [&](int, double gi) { n2 += gi * gi; }, lp, gd);
         if (isfinite(lp) && isfinite(sqrt(n2))) break;
         if (tries >= max_tries) { st = 1; break; }
@@ -982,67 +999,71 @@ __global__ void klhr_mh_kernel(const KParams p, double stepsize, int seed_only) 
     const int D = p.D;
     Pcg64 rng;
     rng.sh = p.rng[c * 4 + 0]; rng.sl = p.rng[c * 4 + 1]; rng.ih = p.rng[c * 4 + 2]; rng.il = p.rng[c * 4 + 3];
-    double *th = p.theta + c * (long long)D;
-    double *pr = p.d_rho + c * (long long)D;
+    double *th = p.theta, *pr = p.d_rho;          // element i of this chain: [kix(p, c, i)]
+#define KI(i) kix(p, c, (i))
     long long draw = p.counters[c * 4 + 0];
     double acc = p.acc[c];
     if (seed_only) {
-        for (int i = 0; i < D; i++) th[i] = 0.0 + 0.1 * rng_std_normal(rng);     // mcmc.py:15
+        for (int i = 0; i < D; i++) th[KI(i)] = 0.0 + 0.1 * rng_std_normal(rng);     // mcmc.py:15
         draw = 0; acc = 0;
     }
     for (int it = 0; it < (seed_only ? 0 : p.n_iters); ++it) {
         draw += 1;
-        for (int i = 0; i < D; i++) pr[i] = rng_std_normal(rng);
-        for (int i = 0; i < D; i++) pr[i] = add_rn(th[i], mul_rn(pr[i], stepsize));
+        for (int i = 0; i < D; i++) pr[KI(i)] = rng_std_normal(rng);
+        for (int i = 0; i < D; i++) pr[KI(i)] = add_rn(th[KI(i)], mul_rn(pr[KI(i)], stepsize));
         double lpp, lpc, gd;
-        model_eval<MODEL>(p.md, [&](int i, double &xi, double &ri) { xi = pr[i]; ri = 0.0; }, INFINITY, NoSink(), lpp, gd);
-        model_eval<MODEL>(p.md, [&](int i, double &xi, double &ri) { xi = th[i]; ri = 0.0; }, INFINITY, NoSink(), lpc, gd);
+        model_eval<MODEL>(p.md, [&](int i, double &xi, double &ri) { xi = pr[KI(i)]; ri = 0.0; }, INFINITY, NoSink(), lpp, gd);
+        model_eval<MODEL>(p.md, [&](int i, double &xi, double &ri) { xi = th[KI(i)]; ri = 0.0; }, INFINITY, NoSink(), lpc, gd);
         double r = lpp;
         r -= lpc;
         double q1 = 0, q2 = 0;
-        for (int i = 0; i < D; i++) { double z = (th[i] - pr[i]) / stepsize; q1 += z * z; }
-        for (int i = 0; i < D; i++) { double z = (pr[i] - th[i]) / stepsize; q2 += z * z; }
+        for (int i = 0; i < D; i++) { double z = (th[KI(i)] - pr[KI(i)]) / stepsize; q1 += z * z; }
+        for (int i = 0; i < D; i++) { double z = (pr[KI(i)] - th[KI(i)]) / stepsize; q2 += z * z; }
         r += -0.5 * q1;
         r -= -0.5 * q2;
         const double logu = log(rng_uniform(rng));
         const double mn = (r != r) ? r : (r < 0 ? r : 0.0);
         const int a = logu < mn ? 1 : 0;
         const double ad = (double)a, na = (double)(1 - a);
-        for (int i = 0; i < D; i++) th[i] = add_rn(mul_rn(ad, pr[i]), mul_rn(na, th[i]));
+        for (int i = 0; i < D; i++) th[KI(i)] = add_rn(mul_rn(ad, pr[KI(i)]), mul_rn(na, th[KI(i)]));
         acc += (ad - acc) / (double)draw;
         if (p.draws) {
             double *out = p.draws + ((long long)it * p.C + c) * D;
-            for (int i = 0; i < D; i++) out[i] = th[i];
+            for (int i = 0; i < D; i++) out[i] = th[KI(i)];
         }
     }
     p.rng[c * 4 + 0] = rng.sh; p.rng[c * 4 + 1] = rng.sl; p.rng[c * 4 + 2] = rng.ih; p.rng[c * 4 + 3] = rng.il;
     p.counters[c * 4 + 0] = draw;
     p.acc[c] = acc;
+#undef KI
 }
 
 #ifndef KLHR_HOT_TU
 // rank permutation of cov after klhr_set_state(KLHR_F_COV)
-__global__ void klhr_rank_kernel(const double *cov, int *rank, int C, int D) {
+__global__ void klhr_rank_kernel(const KParams p) {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const double *cv = cov + c * (long long)D;
-    int *rk = rank + c * (long long)D;
+    if (c >= p.C) return;
+    const int D = p.D;
     for (int i = 0; i < D; i++) {
         int r = 0;
-        for (int j = 0; j < D; j++) r += (cv[j] > cv[i] || (cv[j] == cv[i] && j < i)) ? 1 : 0;
-        rk[i] = r;
+        const double ci = p.cov[kix(p, c, i)];
+        for (int j = 0; j < D; j++) { const double cj = p.cov[kix(p, c, j)]; r += (cj > ci || (cj == ci && j < i)) ? 1 : 0; }
+        p.rank[kix(p, c, i)] = r;
     }
 }
 
 // pooled-adaptation sufficient statistics over this GPU's chains: out = [n, sum m_i (D), sum (v_i + m_i^2) (D)]
 // (chains whose state has gone non-finite — status bit 1, the reference's own failure mode — are left out of the pool)
-__global__ void klhr_pool_kernel(const double *om_m, const double *om_v, const long long *counters, const int *status, int C, int D, double *out) {
+__global__ void klhr_pool_kernel(const KParams p, double *out) {
     const int i = blockIdx.x;        // coordinate
+    const int C = p.C, D = p.D;
+    const long long *counters = p.counters;
+    const int *status = p.status;
     double sm = 0, sq = 0, sn = 0;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         if (status[c] & 2) continue;
         double n = (double)counters[c * 4 + 1];
-        double m = om_m[(long long)c * D + i], v = om_v[(long long)c * D + i];
+        double m = p.om_m[kix(p, c, i)], v = p.om_v[kix(p, c, i)];
         sm += n * m;
         sq += n * (v + m * m);
         sn += n;
@@ -1094,32 +1115,32 @@ __global__ __launch_bounds__(64) void klhr_gram_mfma_kernel(const double *X, lon
     }
 }
 
-__global__ void klhr_pool_apply_full_kernel(const double *mean_in, const double *cov_in, const double *evec_in, const double *eval_in,
-                                            double *mean, double *cov, double *eigvecs, double *eigvals, int *rank, int C, int D,
-                                            int ncol) {
+__global__ void klhr_pool_apply_full_kernel(const KParams p, const double *mean_in, const double *cov_in, const double *evec_in, const double *eval_in) {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    if (c >= p.C) return;
+    const int D = p.D, ncol = p.ncol;
     for (int i = 0; i < D; i++) {
-        mean[c * (long long)D + i] = mean_in[i];
-        cov[c * (long long)D + i] = cov_in[i];
-        for (int j = 0; j < ncol; j++) eigvecs[(c * (long long)D + i) * ncol + j] = evec_in[i * ncol + j];
+        p.mean[kix(p, c, i)] = mean_in[i];
+        p.cov[kix(p, c, i)] = cov_in[i];
+        for (int j = 0; j < ncol; j++) p.eigvecs[kix2(p, c, i, j, ncol)] = evec_in[i * ncol + j];
     }
-    for (int j = 0; j < ncol; j++) eigvals[c * (long long)ncol + j] = eval_in[j];
+    for (int j = 0; j < ncol; j++) p.eigvals[c * (long long)ncol + j] = eval_in[j];
     for (int i = 0; i < D; i++) {
         int r = 0;
         for (int j = 0; j < D; j++) r += (cov_in[j] > cov_in[i] || (cov_in[j] == cov_in[i] && j < i)) ? 1 : 0;
-        rank[c * (long long)D + i] = r;
+        p.rank[kix(p, c, i)] = r;
     }
 }
 
-__global__ void klhr_pool_apply_kernel(const double *mean_in, const double *cov_in, double *mean, double *cov, int *rank, int C, int D) {
+__global__ void klhr_pool_apply_kernel(const KParams p, const double *mean_in, const double *cov_in) {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    for (int i = 0; i < D; i++) { mean[c * (long long)D + i] = mean_in[i]; cov[c * (long long)D + i] = cov_in[i]; }
+    if (c >= p.C) return;
+    const int D = p.D;
+    for (int i = 0; i < D; i++) { p.mean[kix(p, c, i)] = mean_in[i]; p.cov[kix(p, c, i)] = cov_in[i]; }
     for (int i = 0; i < D; i++) {
         int r = 0;
         for (int j = 0; j < D; j++) r += (cov_in[j] > cov_in[i] || (cov_in[j] == cov_in[i] && j < i)) ? 1 : 0;
-        rank[c * (long long)D + i] = r;
+        p.rank[kix(p, c, i)] = r;
     }
 }
 

@@ -1,0 +1,51 @@
+// klhr_split.hip — one translation unit per sampler variant of the split-phase pipeline (klhr_split.hpp).
+// Compiled by klhr_amd/build.py with -DKLHR_VARIANT={0,1,2}.  The kernels are far smaller than the monolithic ones of
+// klhr_hot.hip (the fit kernels hold the optimiser state and seven line sums, nothing else), so over-relaxation and the
+// three separable models share a unit.
+#define KLHR_HOT_TU 1
+#include "klhr_split.hpp"
+
+#ifndef KLHR_VARIANT
+#error "compile with -DKLHR_VARIANT=0|1|2"
+#endif
+#define KLHR_CAT2_(a, b) a##b
+#define KLHR_CAT2(a, b) KLHR_CAT2_(a, b)
+
+namespace klhr {
+
+template <int MODEL>
+static void launch_split_model(const KParams &kp, int what, bool overrelaxed, int do_tail, int do_head, hipStream_t stream) {
+    constexpr int V = KLHR_VARIANT;
+    const unsigned tiles = (unsigned)((kp.C + 63) / 64);          // fit / probe kernels: 64 chains per wavefront
+    const unsigned stiles = (unsigned)(kp.Cpad / kp.tw);          // streaming kernel: one wavefront per tile of tw chains
+    const dim3 block(64);
+    // fit launches: at most `fit_waves` wavefronts (the resident capacity); chains beyond 64 per wavefront go through the queue
+    const unsigned fitgrid = kp.fit_waves > 0 && (unsigned)kp.fit_waves < tiles ? (unsigned)kp.fit_waves : tiles;
+    if (what == 1) {
+        hipLaunchKernelGGL((klhr_fit1_kernel<MODEL>), dim3(fitgrid), block, 0, stream, kp);
+    } else if (what == 2) {
+        hipLaunchKernelGGL((klhr_fit2_kernel<MODEL, V>), dim3(fitgrid), block, 0, stream, kp);
+    } else if (what == 3) {
+        hipLaunchKernelGGL((klhr_probe_kernel<MODEL, V>), dim3(tiles), block, 0, stream, kp);
+    } else {
+        const size_t lds = ((size_t)kp.D * kp.tw + KLHR_ZTAB_DOUBLES) * sizeof(double);
+        if (overrelaxed) {
+            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)klhr_stream_kernel<MODEL, true, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((klhr_stream_kernel<MODEL, true, V>), dim3(stiles), block, lds, stream, kp, do_tail, do_head);
+        } else {
+            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)klhr_stream_kernel<MODEL, false, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((klhr_stream_kernel<MODEL, false, V>), dim3(stiles), block, lds, stream, kp, do_tail, do_head);
+        }
+    }
+}
+
+// what: 0 streaming kernel (do_tail / do_head), 1 mode search, 2 KL fit, 3 KL / line probe
+void KLHR_CAT2(launch_split_v, KLHR_VARIANT)(const KParams &kp, int model_id, int what, bool overrelaxed, int do_tail, int do_head, hipStream_t stream) {
+    switch (model_id) {
+    case KLHR_MODEL_FUNNEL: launch_split_model<MODEL_FUNNEL>(kp, what, overrelaxed, do_tail, do_head, stream); break;
+    case KLHR_MODEL_ILL_NORMAL: launch_split_model<MODEL_ILL_NORMAL>(kp, what, overrelaxed, do_tail, do_head, stream); break;
+    default: launch_split_model<MODEL_NORMAL>(kp, what, overrelaxed, do_tail, do_head, stream); break;
+    }
+}
+
+}  // namespace klhr

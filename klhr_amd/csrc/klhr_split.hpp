@@ -1,0 +1,827 @@
+// klhr_split.hpp — the split-phase pipeline: KLHRSINH.draw() (klhr_sinh.py:262-289) for line-separable targets.
+//
+// For funnel, ill-normal and normal (stan/funnel.stan:4-10, stan/ill-normal.stan:4-11, stan/normal.stan:4-8) the log
+// density restricted to a line theta + t*rho is a closed form in t through a handful of per-line sums:
+//     sum_i (a_i + t r_i)^2 = A + 2tB + t^2 C,      sum_i (a_i + t r_i) r_i = B + tC
+// (a = theta or theta/s, r = rho or rho/s).  One O(D) pass per iteration produces (A, B, C, max|a|, max|r|, ...), after
+// which every one of the ~120 log-density(+gradient) evaluations of a fit (klhr_sinh.py:163-201) costs O(1) instead of
+// O(D).  The element-wise gradient clip of _logp_grad (klhr_sinh.py:158-161) is inactive whenever
+// max_i |g_i(t)| <= clip, which the two maxima bound; the rare evaluation where that bound fails (measured on the
+// reference: 1 in 2 000-5 000 KL evaluations) is recomputed by the exact element-wise loop, so clipping semantics are kept.
+//
+// With the fit reduced to O(1) state per chain the iteration splits into three kernels with the mapping each part wants:
+//   klhr_stream_kernel  lane = chain, wavefront = tile of 64 chains.  Everything that is O(D) per chain and sequential
+//                       in the coordinate index (NumPy's summation orders, the PCG64 stream): MH accept/reject + theta
+//                       update + OnlineMoments + CCIPCA (+ window closure) of iteration k, then the direction draw, the
+//                       line sums and the fit's five normals of iteration k+1.  The chain state lives in HBM in a TILED
+//                       layout [tile][coordinate][64 lanes]: lane-per-chain access to coordinate i of 64 chains is one
+//                       contiguous 512-byte segment.  This kernel moves all the algorithmic bytes of an iteration.
+//   klhr_fit1_kernel    the 1-D mode search (klhr_sinh.py:183-187), opt_advance<N = 1>
+//   klhr_fit2_kernel    the KL fit (klhr_sinh.py:194-199), opt_advance<N = 4 | 3 | 2>, 8 Gauss-Hermite nodes per lane
+//                       Both fit kernels are lane-per-task with a device-side QUEUE: a lane whose fit has converged
+//                       claims the next chain (wave-aggregated atomic) instead of idling until the slowest chain of
+//                       its wavefront is done.  Which lane runs a chain has no influence on the chain's arithmetic.
+// Results: RNG stream, direction, OnlineMoments, CCIPCA, closures bit-exact as in the monolithic kernels; objective values
+// agree with the element-wise loops to rounding (closed form instead of a D-term sum), inside the stated tolerances.
+#pragma once
+#include "klhr_lane_kernel.hpp"
+
+namespace klhr {
+
+// (per-chain fit record F_*: klhr_kernels.hpp)
+struct LineStat { double v0, r0, A, B, C, m0, m1; };
+
+#define KLHR_FB(p, f, c) (p).fitbuf[(long long)(f) * (p).Cpad + (c)]
+
+__device__ __forceinline__ LineStat load_stat(const KParams &p, long long c) {
+    LineStat s;
+    s.v0 = KLHR_FB(p, F_S0, c); s.r0 = KLHR_FB(p, F_S1, c); s.A = KLHR_FB(p, F_S2, c); s.B = KLHR_FB(p, F_S3, c);
+    s.C = KLHR_FB(p, F_S4, c); s.m0 = KLHR_FB(p, F_S5, c); s.m1 = KLHR_FB(p, F_S6, c);
+    return s;
+}
+
+// log density and clip(grad).rho at theta + t*rho from the line sums.  Returns true when the element-wise clip at +-cl may
+// be active at this point (the caller then recomputes the point with exact_points4); CLIP = false: no clipping
+// (logp_grad_rho, klhr_sinh.py:178-180; klhr.py's raw gradient; log-density values of the MH step).
+template <int MODEL, bool CLIP>
+__device__ __forceinline__ bool line_point(const KParams &p, const LineStat &s, double t, double cl, double &logp, double &gdot) {
+    double S = fma(t, fma(t, s.C, 2.0 * s.B), s.A);
+    S = S < 0.0 ? 0.0 : S;                       // a sum of squares: rounding of the closed form may leave -1e-17
+    const double Sr = fma(t, s.C, s.B);
+    if constexpr (MODEL == MODEL_FUNNEL) {
+        const double Da = (double)p.md.n;
+        const double v = fma(t, s.r0, s.v0);
+        const double ev = exp(-v);
+        const double g0 = -v * (1.0 / 9.0) - 0.5 * Da + 0.5 * ev * S;
+        logp = -v * v * (1.0 / 18.0) - 0.5 * Da * v - 0.5 * ev * S;
+        gdot = (CLIP ? clipc(g0, cl) : g0) * s.r0 - ev * Sr;
+        if constexpr (CLIP) return !(ev * (s.m0 + fabs(t) * s.m1) <= cl);
+        return false;
+    } else {
+        logp = -0.5 * S;
+        gdot = -Sr;
+        if constexpr (CLIP) return !(s.m0 + fabs(t) * s.m1 <= cl);
+        return false;
+    }
+}
+
+// The exact element-wise evaluation of four points of one chain's line (model_eval's arithmetic, in index order), from
+// the tiled theta / direction rows in HBM: the rare path behind line_point's clip bound.  Out of line, by value.
+struct Pts4 { double lp[4], gd[4]; };
+template <int MODEL>
+__device__ __attribute__((noinline)) Pts4 exact_points4(const double *theta_t, const double *r_t, const double *aux, int D, int W, int nmodel,
+                                                        double nn, double t0, double t1, double t2, double t3, double cl) {
+    const double t[4] = {t0, t1, t2, t3};
+    Pts4 o;
+    if constexpr (MODEL == MODEL_FUNNEL) {
+        const double th0 = theta_t[0], r0 = r_t[0] / nn;
+        const double Da = (double)nmodel;
+        double v[4], ev[4], ss[4], gd[4];
+#pragma unroll
+        for (int n = 0; n < 4; n++) { v[n] = fma(t[n], r0, th0); ev[n] = exp(-v[n]); ss[n] = 0.0; gd[n] = 0.0; }
+        for (int i = 1; i < D; i++) {
+            const double a = theta_t[(long long)i * W], r = r_t[(long long)i * W] / nn;
+#pragma unroll
+            for (int n = 0; n < 4; n++) {
+                const double xi = fma(t[n], r, a);
+                ss[n] += xi * xi;
+                gd[n] += clipc(-ev[n] * xi, cl) * r;
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < 4; n++) {
+            const double g0 = -v[n] * (1.0 / 9.0) - 0.5 * Da + 0.5 * ev[n] * ss[n];
+            o.gd[n] = clipc(g0, cl) * r0 + gd[n];
+            o.lp[n] = -v[n] * v[n] * (1.0 / 18.0) - 0.5 * Da * v[n] - 0.5 * ev[n] * ss[n];
+        }
+    } else {
+        double acc[4] = {0, 0, 0, 0}, gd[4] = {0, 0, 0, 0};
+        for (int i = 0; i < D; i++) {
+            const double a = theta_t[(long long)i * W], r = r_t[(long long)i * W] / nn;
+            const double is = MODEL == MODEL_ILL_NORMAL ? aux[i] : 1.0;
+#pragma unroll
+            for (int n = 0; n < 4; n++) {
+                const double xi = fma(t[n], r, a);
+                double gi;
+                if constexpr (MODEL == MODEL_ILL_NORMAL) { const double z = xi * is; acc[n] += z * z; gi = -z * is; }
+                else { acc[n] += xi * xi; gi = -xi; }
+                gd[n] += clipc(gi, cl) * r;
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < 4; n++) { o.gd[n] = gd[n]; o.lp[n] = -0.5 * acc[n]; }
+    }
+    return o;
+}
+
+// tiled row of chain c: element i of a [C][D] array sits at base + i*W
+__device__ __forceinline__ long long tile_base(long long c, int D, int W) { return (c / W) * (long long)D * W + (c % W); }
+
+// ---- KL(eta) value + gradient (klhr_sinh.py:163-176) from the line sums: the lane kernel's node groups (same per-node
+// arithmetic, same fixed summation tree ((0+1)+(2+3))+((4+5)+(6+7))) with line_point in place of the O(D) loop
+#pragma clang fp contract(off)
+template <int MODEL, bool SUB>
+__device__ __forceinline__ void split_kl_group(const KParams &p, const LineStat &st, long long c, double nn, double x0, const KLScal &k,
+                                               const double *asx, const double *wq, double (&part)[5]) {
+    double sh[4], ch[4], lch[4], t[4], av[4], logp[4], gdot[4];
+    const double cl = SUB ? p.grad_clip : p.scale_clip;
+    bool need = false;
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        const double a = (asx[n] + k.esh) * k.invd;
+        const double ac = clipc(a, p.scale_clip);
+        const double E = exp(ac), Ei = fast_rcp(E);
+        sh[n] = 0.5 * (E - Ei);
+        ch[n] = 0.5 * (E + Ei);
+        lch[n] = log_cosh_from_exp(fabs(ac), fmin(E, Ei));
+        t[n] = fma(k.s_, sh[n], x0);
+        av[n] = a;
+        need = line_point<MODEL, true>(p, st, t[n], cl, logp[n], gdot[n]) || need;
+    }
+    if (__any(need)) {
+        if (need) {
+            const long long tb = tile_base(c, p.D, p.tw);
+            const Pts4 e = exact_points4<MODEL>(p.theta + tb, p.d_rho + tb, p.md.aux, p.D, p.tw, p.md.n, nn, t[0], t[1], t[2], t[3], cl);
+#pragma unroll
+            for (int n = 0; n < 4; n++) { logp[n] = e.lp[n]; gdot[n] = e.gd[n]; }
+        }
+    }
+    double cc[4][5];
+#pragma unroll
+    for (int n = 0; n < 4; n++) kl_node_terms<SUB>(wq[n], av[n], sh[n], ch[n], lch[n], logp[n], gdot[n], k, cc[n]);
+#pragma unroll
+    for (int j = 0; j < 5; j++) part[j] = (cc[0][j] + cc[1][j]) + (cc[2][j] + cc[3][j]);
+}
+
+// KLHR objective (klhr.py:109-124): raw gradient, so the closed form needs no clip bound
+template <int MODEL>
+__device__ __forceinline__ void split_gauss_group(const KParams &p, const LineStat &st, double m, double s_, const double *xq, const double *wq,
+                                                  double (&part)[5]) {
+    double c3[4][3];
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        const double t = fma(s_, xq[n], m);
+        double logp, gdot;
+        (void)line_point<MODEL, false>(p, st, t, INFINITY, logp, gdot);
+        const double wgr = wq[n] * gdot;
+        c3[n][0] = wq[n] * logp;
+        c3[n][1] = wgr;
+        c3[n][2] = (wgr * xq[n]) * s_;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) part[j] = (c3[0][j] + c3[1][j]) + (c3[2][j] + c3[3][j]);
+    part[3] = part[4] = 0.0;
+}
+#pragma clang fp contract(fast)
+
+template <int MODEL, int VARIANT>
+__device__ __forceinline__ void split_eval_kl(const KParams &p, const LineStat &st, long long c, double nn, const double *xt, double &f, double *g) {
+    double acc5[5] = {0, 0, 0, 0, 0};
+    if constexpr (VARIANT == VAR_GAUSS) {
+        const double sg = exp(clipc(xt[1], p.scale_clip));
+#pragma unroll 1
+        for (int h = 0; h < 2; h++) {
+            double part[5];
+            split_gauss_group<MODEL>(p, st, xt[0], sg, p.xq + 4 * h, p.wq + 4 * h, part);
+#pragma unroll
+            for (int j = 0; j < 5; j++) acc5[j] = h == 0 ? part[j] : add_rn(acc5[j], part[j]);
+        }
+        f = -(acc5[0] + xt[1]); g[0] = -acc5[1]; g[1] = -(acc5[2] + 1.0); g[2] = g[3] = 0.0;
+    } else {
+        constexpr bool SUB = VARIANT == VAR_SUB;
+        const KLScal k = kl_scalars<SUB>(p, xt[1], xt[2], xt[3]);
+#pragma unroll 1
+        for (int h = 0; h < 2; h++) {
+            double part[5];
+            split_kl_group<MODEL, SUB>(p, st, c, nn, xt[0], k, p.asx + 4 * h, p.wq + 4 * h, part);
+#pragma unroll
+            for (int j = 0; j < 5; j++) acc5[j] = h == 0 ? part[j] : add_rn(acc5[j], part[j]);
+        }
+        f = acc5[0]; g[0] = acc5[1]; g[1] = acc5[2]; g[2] = acc5[3]; g[3] = acc5[4];
+    }
+}
+
+// ---- the fit queue.
+// A fit launch has `grid` wavefronts; wavefront w starts on chains 64w .. 64w+63 (no atomics).  Chains from 64*grid on
+// (launches with more chains than resident lanes) wait in KLHR_NQ sub-queues — contiguous ranges of chains, each with its own
+// head counter on its own 128-byte line, so that claims from different wavefronts mostly hit different L2 channels.  A lane
+// whose fit has converged asks for the next chain; the wavefront's leader claims for all askers with ONE atomic add on the
+// wavefront's current sub-queue, issued one pass AHEAD of its use (the evaluation + optimiser step of the pass hide the
+// atomic's latency).  A wavefront that finds a sub-queue exhausted moves to the next; after KLHR_NQ exhausted ones it stops
+// asking.  Which lane runs a chain has no influence on the chain's arithmetic.
+#define KLHR_NQ 64
+#define KLHR_QSTRIDE 32          // unsigned ints between two heads (128 bytes)
+struct FitQueue {
+    unsigned int *heads;         // this stage's KLHR_NQ heads
+    long long q0, L, C;          // first queued chain, chains per sub-queue, number of chains
+    int cur, seen_empty;         // wave-uniform: current sub-queue, consecutive exhausted sub-queues
+    // one pass: begin() issues the claim for the lanes in `want`; end() hands out the chains
+    unsigned long long m;
+    unsigned int basev;
+    int leader;
+};
+__device__ __forceinline__ void fq_init(FitQueue &q, unsigned int *heads, long long q0, int C, int wave) {
+    q.heads = heads; q.q0 = q0; q.C = C;
+    const long long rest = C > q0 ? C - q0 : 0;
+    q.L = (rest + KLHR_NQ - 1) / KLHR_NQ;
+    q.cur = wave % KLHR_NQ;
+    q.seen_empty = rest > 0 ? 0 : KLHR_NQ;
+    q.m = 0; q.basev = 0; q.leader = 0;
+}
+__device__ __forceinline__ void fq_begin(FitQueue &q, bool want, int lane) {
+    q.m = q.seen_empty >= KLHR_NQ ? 0ull : __ballot(want);
+    if (q.m) {
+        q.leader = __ffsll((long long)q.m) - 1;
+        if (lane == q.leader) q.basev = atomicAdd(q.heads + q.cur * KLHR_QSTRIDE, (unsigned int)__popcll(q.m));
+    }
+}
+// returns the chain for this lane (-1: none); lanes that asked and got none keep asking until every sub-queue is exhausted
+__device__ __forceinline__ long long fq_end(FitQueue &q, bool want, int lane, bool &exhausted) {
+    exhausted = q.seen_empty >= KLHR_NQ;
+    if (!q.m) return -1;
+    const unsigned int base = (unsigned int)__shfl((int)q.basev, q.leader);
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(q.m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)q.m, 0u));
+    const long long lo = q.q0 + (long long)q.cur * q.L;
+    long long hi = lo + q.L;
+    if (hi > q.C) hi = q.C;
+    const long long t = lo + (long long)base + rank;
+    const bool asked = (q.m >> lane) & 1ull;
+    if (lo + (long long)base + __popcll(q.m) >= hi) {          // this sub-queue is (now) exhausted: move on
+        q.cur = (q.cur + 1) % KLHR_NQ;
+        q.seen_empty += 1;
+    } else q.seen_empty = 0;
+    exhausted = q.seen_empty >= KLHR_NQ;
+    return (asked && want && t < hi) ? t : -1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stage 1 of fit(): minimize(logp_grad_rho, x0, BFGS, gtol = 1e-5) (klhr_sinh.py:183-190), one task per lane.
+template <int MODEL>
+__global__ __launch_bounds__(64) void klhr_fit1_kernel(const KParams p) {
+    const int lane = threadIdx.x & 63;
+    Opt o;
+    LineStat st = {0, 0, 0, 0, 0, 0, 0};
+    long long task = (long long)blockIdx.x * 64 + lane;
+    bool live = false, want = false, fresh = task < p.C;
+    int npass = 0, ltrips = 0;
+    const bool diag = (p.flags & FLAG_DIAG) != 0;
+    FitQueue q;
+    fq_init(q, p.qhead, (long long)gridDim.x * 64, p.C, blockIdx.x);
+    for (;;) {
+        fq_begin(q, want, lane);
+        if (fresh) {
+            fresh = false; live = true;
+            st = load_stat(p, task);
+            const double x0v[4] = {KLHR_FB(p, F_X0, task), 0, 0, 0};
+            if (diag) p.d_diag[task * KLHR_NDIAG + KLHR_D_X0] = x0v[0];
+            opt_begin(o, 1, x0v, 1e-5);
+            npass = 0; ltrips = 0;
+        }
+        bool finished = false;
+        if (live) {
+            double f = 0, g[4] = {0, 0, 0, 0};
+            if (opt_cache_hit(o)) { f = o.lf; g[0] = o.lg[0]; }
+            else {
+                double lp, gd;
+                (void)line_point<MODEL, false>(p, st, o.xt[0], INFINITY, lp, gd);
+                f = -lp; g[0] = -gd;
+                opt_cache_store(o, f, g);
+                npass++;
+            }
+            opt_advance<false, 1>(o, f, g);
+            const bool capped = ++ltrips > KLHR_MAX_PASSES;
+            if (o.pc == PC_DONE || capped) {
+                double s = o.H[0];
+                s = (s > 0 ? 1.0 : 0.0) * 0.5 * log(s);
+                KLHR_FB(p, F_MODE, task) = o.xk[0];
+                KLHR_FB(p, F_INIT1, task) = s;
+                KLHR_FB(p, F_PASS, task) = (double)npass;
+                KLHR_FB(p, F_NFEV1, task) = (double)o.nfev;       // (stores only: a load here would stall the whole wavefront's pass)
+                if (capped && o.pc != PC_DONE) atomicOr(&p.status[task], 8);
+                if (diag) {
+                    double *dd = p.d_diag + task * KLHR_NDIAG;
+                    dd[KLHR_D_MODE] = o.xk[0]; dd[KLHR_D_HINV1] = o.H[0]; dd[KLHR_D_NFEV1] = o.nfev; dd[KLHR_D_NIT1] = o.k;
+                    dd[KLHR_D_STATUS1] = o.status; dd[KLHR_D_FALLBACKS] = o.fallbacks;
+                }
+                live = false;
+                finished = true;
+            }
+        }
+        bool exhausted;
+        const long long nt = fq_end(q, want, lane, exhausted);
+        if (want && nt >= 0) { task = nt; fresh = true; want = false; }
+        if (finished) want = true;
+        if (exhausted) want = false;
+        if (!__any(live || fresh || want)) break;
+    }
+}
+
+// Stage 2 of fit(): minimize(KL, init, BFGS, gtol = 1e-3) (klhr_sinh.py:191-201; klhr.py:134-139; sub_klhr_sinh.py:184-192)
+template <int MODEL, int VARIANT>
+__global__ __launch_bounds__(64) void klhr_fit2_kernel(const KParams p) {
+    constexpr int N = VARIANT == VAR_GAUSS ? 2 : (VARIANT == VAR_SUB ? 3 : 4);
+    const int lane = threadIdx.x & 63;
+    Opt o;
+    LineStat st = {0, 0, 0, 0, 0, 0, 0};
+    double nn = 1.0;
+    long long task = (long long)blockIdx.x * 64 + lane;
+    bool live = false, want = false, fresh = task < p.C;
+    int npass = 0, ltrips = 0;
+    const bool diag = (p.flags & FLAG_DIAG) != 0;
+    FitQueue q;
+    fq_init(q, p.qhead + KLHR_NQ * KLHR_QSTRIDE, (long long)gridDim.x * 64, p.C, blockIdx.x);
+    for (;;) {
+        fq_begin(q, want, lane);
+        if (fresh) {
+            fresh = false; live = true;
+            st = load_stat(p, task);
+            nn = KLHR_FB(p, F_NN, task);
+            const double init[4] = {KLHR_FB(p, F_MODE, task), KLHR_FB(p, F_INIT1, task),
+                                    VARIANT == VAR_GAUSS ? 0.0 : KLHR_FB(p, F_N2, task),
+                                    VARIANT == VAR_SINH ? KLHR_FB(p, F_N3, task) : 0.0};
+            if (diag) {
+                double *dd = p.d_diag + task * KLHR_NDIAG;
+                dd[KLHR_D_INIT0] = init[0]; dd[KLHR_D_INIT1] = init[1]; dd[KLHR_D_INIT2] = init[2]; dd[KLHR_D_INIT3] = init[3];
+            }
+            opt_begin(o, N, init, VARIANT == VAR_GAUSS ? 1e-5 : 1e-3);
+            npass = 0; ltrips = 0;
+        }
+        bool finished = false;
+        if (live) {
+            double f = 0, g[4] = {0, 0, 0, 0};
+            if (opt_cache_hit(o)) { f = o.lf; g[0] = o.lg[0]; g[1] = o.lg[1]; g[2] = o.lg[2]; g[3] = o.lg[3]; }
+            else {
+                split_eval_kl<MODEL, VARIANT>(p, st, task, nn, o.xt, f, g);
+                opt_cache_store(o, f, g);
+                npass++;
+            }
+            opt_advance<false, N>(o, f, g);
+            const bool capped = ++ltrips > KLHR_MAX_PASSES;
+            if (o.pc == PC_DONE || capped) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) p.d_eta[task * 4 + k] = o.xk[k];
+                KLHR_FB(p, F_NFEV2, task) = (double)o.nfev;
+                if (capped && o.pc != PC_DONE) atomicOr(&p.status[task], 8);
+                if (diag) {
+                    double *dd = p.d_diag + task * KLHR_NDIAG;
+                    dd[KLHR_D_NFEV2] = o.nfev; dd[KLHR_D_NIT2] = o.k; dd[KLHR_D_STATUS2] = o.status; dd[KLHR_D_FUN2] = o.old_fval;
+                    dd[KLHR_D_FALLBACKS] += o.fallbacks; dd[KLHR_D_PASSES] = KLHR_FB(p, F_PASS, task) + npass;       // (diagnostic launches only)
+                }
+                live = false;
+                finished = true;
+            }
+        }
+        bool exhausted;
+        const long long nt = fq_end(q, want, lane, exhausted);
+        if (want && nt >= 0) { task = nt; fresh = true; want = false; }
+        if (finished) want = true;
+        if (exhausted) want = false;
+        if (!__any(live || fresh || want)) break;
+    }
+}
+
+// KL / line probes of the C ABI (klhr_kl_eval, klhr_line_eval): one evaluation per chain at eta = d_eta
+template <int MODEL, int VARIANT>
+__global__ __launch_bounds__(64) void klhr_probe_kernel(const KParams p) {
+    const long long c = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
+    if (c >= p.C) return;
+    const LineStat st = load_stat(p, c);
+    const double nn = KLHR_FB(p, F_NN, c);
+    double eta[4], f = 0, g[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; k++) eta[k] = p.d_eta[c * 4 + k];
+    for (int rep = 0; rep < p.n_iters; rep++) {
+        if (p.phases & PH_KL) split_eval_kl<MODEL, VARIANT>(p, st, c, nn, eta, f, g);
+        else {
+            double lp, gd;
+            (void)line_point<MODEL, false>(p, st, eta[0], INFINITY, lp, gd);
+            f = -lp; g[0] = -gd; g[1] = g[2] = g[3] = 0.0;
+        }
+    }
+    double *dd = p.d_diag + c * KLHR_NDIAG;
+    dd[0] = f; dd[1] = g[0]; dd[2] = g[1]; dd[3] = g[2]; dd[4] = g[3];
+}
+
+// ------------------------------------------------------------------------------------------------
+// The streaming kernel.  lane = chain; a wavefront owns tile blockIdx.x (W = p.tw chains, W in {16, 32, 64}; lanes >= W idle)
+// of every state array: element i of chain (tile, lane) of a [C][D] array sits at (tile*D + i)*W + lane.  Narrow tiles put
+// more wavefronts — more loads in flight — on the machine when there are few chains; the kernel is bound by memory latency
+// and bandwidth, not by its arithmetic.
+// A row is walked CH elements at a time with all loads of a chunk issued before the first use.
+template <int CH, class T>
+__device__ __forceinline__ void st_load(const T *base, long long stride, int i0, int D, T (&r)[CH]) {
+#pragma unroll
+    for (int k = 0; k < CH; k++) { const int i = i0 + k < D ? i0 + k : D - 1; r[k] = base[(long long)i * stride]; }
+}
+constexpr int ST_CH = 8;          // passes over several arrays
+constexpr int ST_CH1 = 24;        // passes over one array
+
+#pragma clang fp contract(off)      // NumPy's element-wise roundings and summation orders (bit-exact pieces)
+
+// onlinepca.py:13-26 for the chain of this lane.  u = theta - mean in Z (LDS column of the lane, stride W), V = the tile's
+// pca_v rows.  Per component: sums (s, u.v) -> v' = w v + (1-w) u (u.v)/(|v|+tol), sums on v' -> u -= (u.v') v'/(|v'|^2+tol);
+// the deflation pass of component j also gathers the first sums of component j+1.
+__device__ inline void split_pca_update(const KParams &p, double *V, long long n_new, double *Z, int W) {
+    const int D = p.D, K = p.J;
+    const long long lim = n_new < K ? n_new : K;
+    const long long vs = (long long)K * W;
+    double s = 0, udv = 0;
+    bool have_sums = false;
+    for (int col = 0; col < lim; col++) {
+        double *Vc = V + (long long)col * W;
+        if (col == n_new - 1) {
+            for (int i = 0; i < D; i++) Vc[i * vs] = Z[i * W];
+            have_sums = false;
+        } else {
+            const double w = ((double)(n_new - 1) - p.l) / (double)n_new;
+            if (!have_sums) {
+                s = 0; udv = 0;
+                for (int i0 = 0; i0 < D; i0 += ST_CH1) {
+                    double vr[ST_CH1];
+                    st_load<ST_CH1>(Vc, vs, i0, D, vr);
+#pragma unroll
+                    for (int k = 0; k < ST_CH1; k++) if (i0 + k < D) { s += vr[k] * vr[k]; udv += Z[(i0 + k) * W] * vr[k]; }
+                }
+            }
+            const double nv = sqrt(s);
+            double s2 = 0, udv2 = 0;
+            for (int i0 = 0; i0 < D; i0 += ST_CH1) {
+                double vr[ST_CH1];
+                st_load<ST_CH1>(Vc, vs, i0, D, vr);
+#pragma unroll
+                for (int k = 0; k < ST_CH1; k++) if (i0 + k < D) {
+                    const double z = Z[(i0 + k) * W];
+                    const double vn = w * vr[k] + (1 - w) * z * udv / (nv + PCA_TOL);
+                    Vc[(i0 + k) * vs] = vn;
+                    s2 += vn * vn; udv2 += z * vn;
+                }
+            }
+            have_sums = false;
+            if (col + 1 < lim) {          // (the deflation after the last component is never read: onlinepca.py:24-25)
+                const double nv2 = sqrt(s2);
+                const bool next_sums = col + 1 != n_new - 1;       // the next component is updated, not assigned
+                const double *Vn = V + (long long)(col + 1) * W;
+                s = 0; udv = 0;
+                for (int i0 = 0; i0 < D; i0 += ST_CH) {
+                    double vr[ST_CH], vq[ST_CH];
+                    st_load<ST_CH>(Vc, vs, i0, D, vr);
+                    if (next_sums) st_load<ST_CH>(Vn, vs, i0, D, vq);
+#pragma unroll
+                    for (int k = 0; k < ST_CH; k++) if (i0 + k < D) {
+                        const double z = Z[(i0 + k) * W] - udv2 * vr[k] / (nv2 * nv2 + PCA_TOL);
+                        Z[(i0 + k) * W] = z;
+                        if (next_sums) { s += vq[k] * vq[k]; udv += z * vq[k]; }
+                    }
+                }
+                have_sums = next_sums;
+            }
+        }
+    }
+}
+
+// klhr_sinh.py:268-280 (+ the rank permutation multivariate_normal's SVD applies to the following windows' normals)
+__device__ inline void split_close_window(const KParams &p, long long c, long long tb, long long tbe, long long tbv, long long omN, double *Z, int W) {
+    const int D = p.D, K = p.J, nc = p.ncol;
+    for (int i = 0; i < D; i++) {
+        const long long e = tb + (long long)i * W;
+        p.mean[e] = p.om_m[e];
+        double cv = omN > 2 ? p.om_v[e] * (double)omN / (double)(omN - 1) : 1.0;
+        if (p.flags & FLAG_SCALE_DIR_COV) {
+            const double vd = omN > 2 ? p.omd_v[e] * (double)omN / (double)(omN - 1) : 1.0;
+            cv = cv / (p.tol + vd);
+            p.omd_m[e] = 0.0; p.omd_v[e] = 0.0;
+        }
+        p.cov[e] = cv;
+        Z[i * W] = cv;
+        p.om_m[e] = 0.0; p.om_v[e] = 0.0;
+    }
+    for (int i = 0; i < D; i++) {
+        const double ci = Z[i * W];
+        int r = 0;
+        for (int j = 0; j < D; j++) { const double cj = Z[j * W]; r += (cj > ci || (cj == ci && j < i)) ? 1 : 0; }
+        p.rank[tb + (long long)i * W] = r;
+    }
+    double vals[4] = {0, 0, 0, 0};
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (j < K) {
+            double s = 0;
+            for (int i = 0; i < D; i++) { const double vi = p.pca_v[tbv + ((long long)i * K + j) * W]; s += vi * vi; }
+            vals[j] = sqrt(s);
+            if (!isfinite(vals[j])) bad = true;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) { if (bad) vals[j] = 0.0; vals[j] += PCA_TOL; }
+    for (int i = 0; i < D; i++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (j < K) {
+            const long long ev = tbv + ((long long)i * K + j) * W;
+            p.eigvecs[tbe + ((long long)i * nc + j) * W] = p.pca_v[ev] / vals[j];
+            p.pca_v[ev] = 0.0;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (j < K) p.eigvals[c * nc + j] = vals[j];
+}
+
+// (still contract(off): the streaming kernel's own arithmetic — accept/reject blend, OnlineMoments, direction draw — is
+//  NumPy's element-wise arithmetic; the closed-form and proposal helpers it calls carry their own setting)
+// element i of the gradient at theta (for OnlineMoments of the gradient, scale_dir_cov): needs the chain's sum of alpha^2
+template <int MODEL>
+__device__ __forceinline__ double grad_elem(const KParams &p, int i, double x, double ev, double g0) {
+    if constexpr (MODEL == MODEL_FUNNEL) return i == 0 ? g0 : -ev * x;
+    else if constexpr (MODEL == MODEL_ILL_NORMAL) { const double is = p.md.aux[i]; return -(x * is) * is; }
+    else return -x;
+}
+
+template <int MODEL, bool OVERRELAX, int VARIANT>
+__global__ __launch_bounds__(64) void klhr_stream_kernel(const KParams p, const int do_tail, const int do_head) {
+    extern __shared__ double lds[];            // [D][W] column scratch (normals, then theta - mean), then the ziggurat tables
+    const int lane = threadIdx.x & 63;
+    const int W = p.tw;
+    const long long c = (long long)blockIdx.x * W + lane;
+    const int D = p.D, nc = p.ncol, K = p.J;
+    double *Z = lds + lane;
+    double *zwi = lds + (size_t)D * W;
+    uint64_t *zki = reinterpret_cast<uint64_t *>(zwi + 256);
+    if (do_head && (p.phases & PH_DIR)) {
+        for (int i = lane; i < 256; i += 64) { zwi[i] = KLHR_ZIG_WI[i]; zki[i] = KLHR_ZIG_KI[i]; }
+        KLHR_WAVE_SYNC();
+    }
+    if (blockIdx.x == 0) {      // empty the sub-queues of the two fit launches that follow
+        p.qhead[lane * KLHR_QSTRIDE] = 0;
+        p.qhead[(KLHR_NQ + lane) * KLHR_QSTRIDE] = 0;
+    }
+    if (lane >= W || c >= p.C) return;
+    const long long tb = (long long)blockIdx.x * D * W + lane;
+    const long long tbe = (long long)blockIdx.x * D * nc * W + lane;
+    const long long tbv = (long long)blockIdx.x * D * K * W + lane;
+    const bool diag = (p.flags & FLAG_DIAG) != 0;
+
+    Pcg64 rng;
+    rng.sh = p.rng[c * 4 + 0]; rng.sl = p.rng[c * 4 + 1]; rng.ih = p.rng[c * 4 + 2]; rng.il = p.rng[c * 4 + 3];
+    long long draw = p.counters[c * 4 + 0], omN = p.counters[c * 4 + 1], pcan = p.counters[c * 4 + 2];
+    int cidx = (int)p.counters[c * 4 + 3];
+    double acc = p.acc[c];
+    double sm_x = 0, sm_cnt = 0, moved_f = 0;
+    int Kc = p.K;
+    if (VARIANT == VAR_GAUSS) { sm_x = p.kstate[c * 4 + 0]; sm_cnt = p.kstate[c * 4 + 1]; Kc = (int)p.kstate[c * 4 + 2]; moved_f = p.kstate[c * 4 + 3]; }
+
+    // =================================================================== tail of iteration k (klhr_sinh.py:266-287)
+    if (do_tail) {
+        // grad_evals += nfev1 + 8 nfev2 of the fit that preceded this tail (klhr_sinh.py:188,200)
+        if (p.phases & PH_FIT) p.grad_evals[c] += (long long)KLHR_FB(p, F_NFEV1, c) + 8 * (long long)KLHR_FB(p, F_NFEV2, c);
+        const bool mh = (p.phases & PH_MH) != 0, adapt = (p.phases & PH_ADAPT) != 0;
+        double zp = 0.0, ad = 0.0, na = 1.0, nn = 1.0;
+        if (mh) {
+            const LineStat st = load_stat(p, c);
+            nn = KLHR_FB(p, F_NN, c);
+            double eta[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) eta[k] = p.d_eta[c * 4 + k];
+            draw += 1;
+            if constexpr (VARIANT == VAR_GAUSS && OVERRELAX) { const ZpOut zo = gauss_overrelaxed_zp_call(rng, eta[0], eta[1], Kc, p.scale_clip); zp = zo.zp; rng = zo.rng; }
+            else if constexpr (VARIANT == VAR_GAUSS) zp = gauss_zp<false>(rng, eta, Kc, p.scale_clip);
+            else if constexpr (OVERRELAX) { const ZpOut zo = overrelaxed_zp_call(rng, eta[0], eta[1], eta[2], eta[3], p.K, p.tol, p.scale_clip, VARIANT == VAR_SUB); zp = zo.zp; rng = zo.rng; }
+            else zp = sa_T(rng_std_normal_call(rng), eta, p.tol, p.scale_clip, VARIANT == VAR_SUB);
+            double lp_p, lp_c, gd_;
+            (void)line_point<MODEL, false>(p, st, zp, INFINITY, lp_p, gd_);
+            (void)line_point<MODEL, false>(p, st, 0.0, INFINITY, lp_c, gd_);
+            double r = lp_p;
+            r -= lp_c;
+            if constexpr (VARIANT == VAR_GAUSS) {
+                const double gm = eta[0], gs = exp(clipc(eta[1], p.scale_clip));
+                r += gauss_logq(0.0, gm, gs);
+                r -= gauss_logq(zp, gm, gs);
+            } else {
+                r += sa_log_q(0.0, eta, p.tol, p.scale_clip, VARIANT == VAR_SUB);
+                r -= sa_log_q(zp, eta, p.tol, p.scale_clip, VARIANT == VAR_SUB);
+            }
+            const double logu = log(rng_uniform(rng));
+            const double mn = (r != r) ? r : (r < 0 ? r : 0.0);      // np.minimum(0, r)
+            const int a = logu < mn ? 1 : 0;
+            ad = (double)a; na = (double)(1 - a);
+            acc += (ad - acc) / (double)draw;
+            if (diag) { double *dd = p.d_diag + c * KLHR_NDIAG; dd[KLHR_D_ZP] = zp; dd[KLHR_D_R] = r; dd[KLHR_D_LOGU] = logu; dd[KLHR_D_ACCEPT] = a; }
+        }
+        bool closed = false;
+        if (adapt && !(p.warmup < p.windowsize) && p.nclos > 0) {
+            closed = draw == p.closures[cidx];
+            if (closed && cidx < p.nclos - 1) cidx++;
+        }
+        const bool upd = adapt && !closed;
+        if (upd) omN += 1;
+        const double w = 1.0 / (double)omN;
+        double *out = p.draws ? p.draws + ((long long)p.draw_slot * p.C + c) * D : nullptr;
+        // ---- pass T1: theta' = a (theta + zp rho) + (1 - a) theta; OnlineMoments(theta'); Z = theta' - mean
+        double d2 = 0.0, ssq = 0.0;
+        bool fin = true;
+        {
+            for (int i0 = 0; i0 < D; i0 += ST_CH) {
+                double th[ST_CH], rr[ST_CH], mm[ST_CH], vv[ST_CH], mn_[ST_CH];
+                st_load<ST_CH>(p.theta + tb, W, i0, D, th);
+                if (mh) st_load<ST_CH>(p.d_rho + tb, W, i0, D, rr);
+                if (upd) { st_load<ST_CH>(p.om_m + tb, W, i0, D, mm); st_load<ST_CH>(p.om_v + tb, W, i0, D, vv); st_load<ST_CH>(p.mean + tb, W, i0, D, mn_); }
+#pragma unroll
+                for (int k = 0; k < ST_CH; k++) {
+                    const int i = i0 + k;
+                    if (i < D) {
+                        double nx = th[k];
+                        if (mh) {
+                            const double rho = rr[k] / nn;
+                            const double thp = add_rn(mul_rn(zp, rho), th[k]);
+                            nx = add_rn(mul_rn(ad, thp), mul_rn(na, th[k]));     // a*thetap + (1-a)*theta
+                            if (VARIANT == VAR_GAUSS) d2 += (nx - th[k]) * (nx - th[k]);
+                            p.theta[tb + (long long)i * W] = nx;
+                        }
+                        if (!isfinite(nx)) fin = false;
+                        if (out) out[i] = nx;
+                        if (i > 0 || MODEL != MODEL_FUNNEL) ssq += nx * nx;
+                        if (upd) {
+                            double mi = mm[k], vi = vv[k];
+                            const double d = nx - mi;
+                            mi += d * w;
+                            vi += -vi * w + d * d * w * (1 - w);
+                            p.om_m[tb + (long long)i * W] = mi;
+                            p.om_v[tb + (long long)i * W] = vi;
+                            Z[i * W] = nx - mn_[k];
+                        }
+                    }
+                }
+            }
+        }
+        if (mh && VARIANT == VAR_GAUSS) moved_f = (sqrt(d2) > 0.0) ? 1.0 : 0.0;
+        if (!fin) atomicOr(&p.status[c], 2);
+        if (closed) {
+            split_close_window(p, c, tb, tbe, tbv, omN, Z, W);
+            omN = 0;
+            pcan = 0;
+            if (VARIANT == VAR_GAUSS) {      // klhr.py:212-214
+                Kc = (int)(sm_x < 1.0 ? 1.0 : (sm_x > 50.0 ? 50.0 : sm_x));
+                sm_x = (double)p.K; sm_cnt = 0.0;
+            }
+        } else if (upd) {
+            if (VARIANT == VAR_GAUSS) smoother_update(sm_x, sm_cnt, moved_f != 0.0);
+            if (p.flags & FLAG_SCALE_DIR_COV) {
+                // OnlineMoments of _logp_grad(theta') (klhr_sinh.py:282-285): clipped at scale_clip (KLHRSINH), grad_clip
+                // (SUBKLHRSINH), raw for KLHR (klhr.py:216)
+                const double clipb = VARIANT == VAR_GAUSS ? INFINITY : (VARIANT == VAR_SUB ? p.grad_clip : p.scale_clip);
+                double ev = 0.0, g0 = 0.0;
+                if constexpr (MODEL == MODEL_FUNNEL) {
+                    const double v = p.theta[tb];
+                    ev = exp(-v);
+                    g0 = -v * (1.0 / 9.0) - 0.5 * (double)p.md.n + 0.5 * ev * ssq;
+                }
+                for (int i0 = 0; i0 < D; i0 += ST_CH) {
+                    double th[ST_CH], mm[ST_CH], vv[ST_CH];
+                    st_load<ST_CH>(p.theta + tb, W, i0, D, th);
+                    st_load<ST_CH>(p.omd_m + tb, W, i0, D, mm);
+                    st_load<ST_CH>(p.omd_v + tb, W, i0, D, vv);
+#pragma unroll
+                    for (int k = 0; k < ST_CH; k++) {
+                        const int i = i0 + k;
+                        if (i < D) {
+                            const double x = clipc(grad_elem<MODEL>(p, i, th[k], ev, g0), clipb);
+                            double mi = mm[k], vi = vv[k];
+                            const double d = x - mi;
+                            mi += d * w;
+                            vi += -vi * w + d * d * w * (1 - w);
+                            p.omd_m[tb + (long long)i * W] = mi;
+                            p.omd_v[tb + (long long)i * W] = vi;
+                        }
+                    }
+                }
+            }
+            pcan += 1;
+            split_pca_update(p, p.pca_v + tbv, pcan, Z, W);
+        }
+    }
+
+    // =================================================================== head of iteration k+1 (klhr_sinh.py:264-265)
+    if (do_head) {
+        double nn = 1.0;
+        LineStat st = {0, 0, 0, 0, 0, 0, 0};
+        double Bs = 0, Cs = 0, m1 = 0;       // direction sums, still on the unnormalised r
+        if (p.phases & PH_DIR) {
+            // eigen_method_one: rng.choice() consumes one uniform BEFORE the D normals (klhr_sinh.py:207,212)
+            const double u_choice = (p.flags & FLAG_EIGEN_ONE) ? pcg_next_double(rng) : 0.0;
+            for (int k = 0; k < D; k++) Z[k * W] = rng_std_normal_tab(rng, zwi, zki);
+            const double *ev = p.eigvals + c * nc;
+            double pj[4] = {0, 0, 0, 0};
+            double sum = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (j < nc) sum += ev[j];
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (j < nc) pj[j] = ev[j] / sum;
+            int pick = -1;
+            if (p.flags & FLAG_EIGEN_ONE) {
+                // rng.choice(n, p=p): cdf = cumsum(p); cdf /= cdf[-1]; searchsorted(cdf, random(), side='right')
+                double cdf[4], accu = 0, last = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) { accu += pj[j]; cdf[j] = accu; if (j == nc - 1) last = accu; }
+                pick = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) if (j < nc && cdf[j] / last <= u_choice) pick = j + 1;
+                if (pick >= nc) pick = nc - 1;
+            }
+            double n2 = 0;
+            for (int i0 = 0; i0 < D; i0 += ST_CH) {
+                double e0[ST_CH], e1[ST_CH], e2[ST_CH], cv[ST_CH], th[ST_CH];
+                int rk[ST_CH];
+                st_load<ST_CH>(p.eigvecs + tbe, (long long)nc * W, i0, D, e0);
+                if (nc > 1) st_load<ST_CH>(p.eigvecs + tbe + W, (long long)nc * W, i0, D, e1);
+                if (nc > 2) st_load<ST_CH>(p.eigvecs + tbe + 2 * W, (long long)nc * W, i0, D, e2);
+                st_load<ST_CH>(p.cov + tb, W, i0, D, cv);
+                st_load<ST_CH>(p.rank + tb, W, i0, D, rk);
+                st_load<ST_CH>(p.theta + tb, W, i0, D, th);
+#pragma unroll
+                for (int k = 0; k < ST_CH; k++) {
+                    const int i = i0 + k;
+                    if (i < D) {
+                        double m = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            if (j < nc) {
+                                const double e = j == 0 ? e0[k] : (j == 1 ? e1[k] : (j == 2 ? e2[k] : p.eigvecs[tbe + ((long long)i * nc + j) * W]));
+                                if (pick >= 0) { if (j == pick) m = e; }
+                                else m += ((VARIANT == VAR_GAUSS || VARIANT == VAR_SLICE) ? ev[j] : pj[j]) * e;      // klhr.py:150
+                            }
+                        }
+                        const double r = m + sqrt(cv[k]) * Z[rk[k] * W];
+                        n2 += (r + p.tol) * (r + p.tol);
+                        p.d_rho[tb + (long long)i * W] = r;
+                        // line sums on (theta, unnormalised r): scaled by 1/nn afterwards
+                        double a = th[k], rs = r;
+                        if constexpr (MODEL == MODEL_ILL_NORMAL) { const double is = p.md.aux[i]; a = a * is; rs = rs * is; }
+                        if (MODEL == MODEL_FUNNEL && i == 0) { st.v0 = a; st.r0 = r; }
+                        else {
+                            st.A = fma(a, a, st.A); Bs = fma(a, rs, Bs); Cs = fma(rs, rs, Cs);
+                            if constexpr (MODEL == MODEL_ILL_NORMAL) { const double is = p.md.aux[i]; a = a * is; rs = rs * is; }     // |g_i| = |x_i| / s_i^2
+                            st.m0 = fmax(st.m0, fabs(a)); m1 = fmax(m1, fabs(rs));
+                            if (a != a || rs != rs) st.m0 = NAN;
+                        }
+                    }
+                }
+            }
+            nn = sqrt(n2);
+        } else {
+            // direction given in d_rho (klhr_fit / klhr_metropolis / probes of the C ABI): nn = 1
+            for (int i0 = 0; i0 < D; i0 += ST_CH) {
+                double rr[ST_CH], th[ST_CH];
+                st_load<ST_CH>(p.d_rho + tb, W, i0, D, rr);
+                st_load<ST_CH>(p.theta + tb, W, i0, D, th);
+#pragma unroll
+                for (int k = 0; k < ST_CH; k++) {
+                    const int i = i0 + k;
+                    if (i < D) {
+                        double a = th[k], rs = rr[k];
+                        if constexpr (MODEL == MODEL_ILL_NORMAL) { const double is = p.md.aux[i]; a = a * is; rs = rs * is; }
+                        if (MODEL == MODEL_FUNNEL && i == 0) { st.v0 = a; st.r0 = rs; }
+                        else {
+                            st.A = fma(a, a, st.A); Bs = fma(a, rs, Bs); Cs = fma(rs, rs, Cs);
+                            if constexpr (MODEL == MODEL_ILL_NORMAL) { const double is = p.md.aux[i]; a = a * is; rs = rs * is; }
+                            st.m0 = fmax(st.m0, fabs(a)); m1 = fmax(m1, fabs(rs));
+                            if (a != a || rs != rs) st.m0 = NAN;
+                        }
+                    }
+                }
+            }
+        }
+        {
+            const double inv = 1.0 / nn;
+            st.B = Bs * inv; st.C = Cs * inv * inv; st.m1 = m1 * inv;
+            if (MODEL == MODEL_FUNNEL) st.r0 = st.r0 / nn;
+        }
+        if (diag && (p.phases & PH_DIR)) {
+            // diagnostics / klhr_random_direction: leave the normalised direction itself in d_rho (nn becomes 1)
+            for (int i = 0; i < D; i++) p.d_rho[tb + (long long)i * W] = p.d_rho[tb + (long long)i * W] / nn;
+            nn = 1.0;
+        }
+        KLHR_FB(p, F_S0, c) = st.v0; KLHR_FB(p, F_S1, c) = st.r0; KLHR_FB(p, F_S2, c) = st.A; KLHR_FB(p, F_S3, c) = st.B;
+        KLHR_FB(p, F_S4, c) = st.C; KLHR_FB(p, F_S5, c) = st.m0; KLHR_FB(p, F_S6, c) = st.m1; KLHR_FB(p, F_NN, c) = nn;
+        if (p.phases & PH_FIT) {
+            // fit() consumes five normals — x0, then size-4 init of which the first two are overwritten (klhr_sinh.py:184,
+            // 191-193); klhr.py's fit draws only x0 (klhr.py:134-139); SUBKLHRSINH draws size 3 (sub_klhr_sinh.py:184)
+            KLHR_FB(p, F_X0, c) = rng_std_normal_call(rng) * p.initscale;
+            double n2v = 0, n3v = 0;
+            if (VARIANT != VAR_GAUSS) {
+                (void)rng_std_normal_call(rng);
+                (void)rng_std_normal_call(rng);
+                n2v = rng_std_normal_call(rng) * p.initscale;
+                if (VARIANT == VAR_SINH) n3v = rng_std_normal_call(rng) * p.initscale;
+            }
+            KLHR_FB(p, F_N2, c) = n2v; KLHR_FB(p, F_N3, c) = n3v;
+        }
+    }
+
+    // ---- store the per-chain scalars
+    p.rng[c * 4 + 0] = rng.sh; p.rng[c * 4 + 1] = rng.sl; p.rng[c * 4 + 2] = rng.ih; p.rng[c * 4 + 3] = rng.il;
+    p.counters[c * 4 + 0] = draw; p.counters[c * 4 + 1] = omN; p.counters[c * 4 + 2] = pcan; p.counters[c * 4 + 3] = cidx;
+    p.acc[c] = acc;
+    if (VARIANT == VAR_GAUSS) { p.kstate[c * 4 + 0] = sm_x; p.kstate[c * 4 + 1] = sm_cnt; p.kstate[c * 4 + 2] = (double)Kc; p.kstate[c * 4 + 3] = moved_f; }
+}
+#pragma clang fp contract(fast)
+
+}  // namespace klhr

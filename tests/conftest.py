@@ -17,6 +17,26 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_generate_tests(metafunc):
+    """Every GPU test runs three times: with the library's own choice of hot-path kernels ("auto"), with the monolithic
+    kernels forced (KLHR_KERNEL=mono: lane-per-chain for D <= 26, octet-per-chain above) and with the split-phase pipeline
+    forced wherever it is supported (KLHR_KERNEL=split: funnel / ill-normal / normal, every variant but the slice
+    sampler).  Tests that pick a mapping themselves (test_gpu_matrix.py) override the variable.  CPU tests run once."""
+    if "kernel_mode" in metafunc.fixturenames:
+        gpu = metafunc.definition.get_closest_marker("gpu") is not None
+        metafunc.parametrize("kernel_mode", ["auto", "mono", "split"] if gpu else ["auto"], indirect=True)
+
+
+@pytest.fixture(autouse=True)
+def kernel_mode(request, monkeypatch):
+    mode = getattr(request, "param", "auto")
+    if mode == "auto":
+        monkeypatch.delenv("KLHR_KERNEL", raising=False)
+    else:
+        monkeypatch.setenv("KLHR_KERNEL", mode)
+    yield mode
+
+
 def golden(name):
     return np.load(os.path.join(GOLDEN, name))
 

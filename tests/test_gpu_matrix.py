@@ -26,7 +26,9 @@ def _spec(name):
 
 @pytest.mark.parametrize("name,lane_ok", CASES)
 @pytest.mark.parametrize("variant,overrelaxed", [(0, False), (0, True), (1, False), (1, True), (2, False), (2, True), (3, False)])
-def test_instantiation_matches_oracle(oracle, monkeypatch, name, lane_ok, variant, overrelaxed):
+def test_instantiation_matches_oracle(oracle, monkeypatch, kernel_mode, name, lane_ok, variant, overrelaxed):
+    if kernel_mode != "auto":
+        pytest.skip("this test selects every mapping itself")
     stem, data = _spec(name)
     seeds = np.arange(100, 100 + NCHAINS, dtype=np.uint64)
     if variant == 3:
@@ -39,10 +41,13 @@ def test_instantiation_matches_oracle(oracle, monkeypatch, name, lane_ok, varian
     ref = np.array([[c.draw() for c in chains] for _ in range(NDRAWS)])         # (draw, chain, D)
     ok = np.isfinite(ref).all(axis=(0, 2))
     assert ok.sum() >= NCHAINS - 2, "oracle chains went non-finite"
-    for kernel in (["lane", "octet"] if (lane_ok and variant != 3) else ["octet"]):
+    kernels = ["lane", "octet"] if (lane_ok and variant != 3) else ["octet"]
+    if stem in ("funnel", "ill-normal", "normal") and variant != 3:
+        kernels.append("split")                                                 # split-phase pipeline (klhr_split.hpp)
+    for kernel in kernels:
         monkeypatch.setenv("KLHR_KERNEL", kernel)
         s = make_sampler(stem, data, NCHAINS, variant=variant, **kw)
-        assert ("lane" in s.kernel_name()) == (kernel == "lane"), s.kernel_name()
+        assert ("lane" in s.kernel_name()) == (kernel == "lane") and ("stream" in s.kernel_name()) == (kernel == "split"), s.kernel_name()
         s.seed(seeds)
         s.step(NDRAWS, record_draws=True)
         got = s.draws(0, NDRAWS)
