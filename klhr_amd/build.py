@@ -15,8 +15,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
-OUT = os.path.join(HERE, "lib", "libklhr_hip.so")
-OBJ = os.path.join(HERE, "lib", "obj")
+OUT = os.environ.get("KLHR_BUILD_OUT") or os.path.join(HERE, "lib", "libklhr_hip.so")      # KLHR_BUILD_OUT: diagnostic builds
+OBJ = os.path.join(os.path.dirname(OUT), "obj" if not os.environ.get("KLHR_BUILD_OUT") else "obj_diag")
 DEPS = ["klhr_api.hip", "klhr_hot.hip", "klhr_split.hip", "klhr_split.hpp", "klhr_kernels.hpp", "klhr_lane_kernel.hpp", "device_opt.hpp", "device_models.hpp",
         "device_rng.hpp", "zig_tables.h", os.path.join("..", "..", "include", "klhr.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"] + os.environ.get("KLHR_EXTRA_FLAGS", "").split()

@@ -124,6 +124,50 @@ __device__ __forceinline__ double rng_std_normal_tab(Pcg64 &g, const double *wi_
     return o.z;
 }
 
+// D standard normals per lane into a strided LDS / memory column (dst[k * stride]), for wavefronts whose lanes own
+// DIFFERENT chains (lane-per-chain kernels).  The ziggurat's fast test fails for 1.2 % of the draws; executed naively,
+// one such lane makes the whole wavefront walk the slow branch (tail / wedge, ~600 instructions) — at 64 lanes that is
+// every second draw.  Here a lane whose draw fails the fast test PARKS (idx, rabs, x) and waits, the others keep drawing,
+// and the slow branch runs once for all parked lanes when every unfinished lane is parked or every KLHR_ZIG_BATCH trips:
+// ~D/KLHR_ZIG_BATCH executions of the slow branch per column instead of ~D/2.  Each lane still consumes its own stream in
+// order: same values, same stream position as Generator.standard_normal() D times.
+#ifndef KLHR_ZIG_BATCH
+#define KLHR_ZIG_BATCH 12
+#endif
+__device__ inline void rng_std_normal_column(Pcg64 &g, double *dst, int stride, int D, const double *wi_l, const uint64_t *ki_l) {
+    int k = 0, idx = 0, trip = 0;
+    uint64_t rabs = 0;
+    double x = 0.0;
+    bool parked = false;
+    for (;;) {
+        const bool todo = k < D;
+        if (todo && !parked) {
+            uint64_t r = pcg_next64(g);
+            idx = (int)(r & 0xff);
+            r >>= 8;
+            const int sign = (int)(r & 1);
+            rabs = (r >> 1) & 0x000fffffffffffffULL;
+            x = (double)rabs * wi_l[idx];
+            if (sign) x = -x;
+            if (rabs < ki_l[idx]) { dst[(long long)k * stride] = x; k++; }
+            else parked = true;
+        }
+        ++trip;
+        const bool any_parked = __any(parked);
+        const bool all_stuck = !__any(k < D && !parked);
+        if (any_parked && (all_stuck || trip % KLHR_ZIG_BATCH == 0)) {
+            if (parked) {
+                const NormOut o = rng_std_normal_slow(g, idx, rabs, x);
+                g = o.g;
+                dst[(long long)k * stride] = o.z;
+                k++;
+                parked = false;
+            }
+        }
+        if (!__any(k < D)) break;
+    }
+}
+
 // Generator.uniform() == 0.0 + (1.0 - 0.0) * next_double
 __device__ __forceinline__ double rng_uniform(Pcg64 &g) { return pcg_next_double(g); }
 

@@ -280,9 +280,9 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
         // Tile width of the streaming kernel: 64 lanes per tile use the whole wavefront, narrower tiles put more wavefronts —
         // more loads in flight — on the machine.  The kernel is bound by memory latency, so: at least ~2 wavefronts per SIMD
         // (2048 tiles) and at most ~24 KB of LDS column scratch per tile, down to 16 chains per tile.
-        int tw = 64;
-        while (tw > 16 && ((s->C + tw - 1) / tw < 2048 || (size_t)D * tw * 8 > 24 * 1024)) tw /= 2;
-        if (const char *e = getenv("KLHR_TILE")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) tw = v; }
+        int tw = (s->C + 63) / 64 < 1024 ? 16 : 64;
+        if (const char *e = getenv("KLHR_TILE")) { const int v = atoi(e); if (v == 16 || v == 64) tw = v; }
+        if (((size_t)D * tw + 512) * 8 > 160 * 1024) tw = 16;       // (one column block + the tables must fit a CU's LDS)
         s->tw = tw;
     }
     s->Cp = s->split ? ((size_t)s->C + s->tw - 1) / s->tw * s->tw : (size_t)s->C;
@@ -310,6 +310,13 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
     k.C = s->C; k.D = D; k.S = S; k.ncol = s->ncol; k.J = cfg->J;
     k.tiled = s->split ? 1 : 0; k.tw = s->tw; k.Cpad = (long long)s->Cp; k.draw_slot = 0;
     if (s->split) { TRY(dalloc(s, &k.fitbuf, (size_t)F_NFIELDS * C)); TRY(dalloc(s, &k.qhead, 2 * 64 * 32)); }
+    {   // streaming kernel: as many tiles per workgroup (1-4 wavefronts) as fit 160 KB of LDS next to the shared 4 KB ziggurat
+        // tables; small column blocks: 4 wavefronts per workgroup, several workgroups per CU
+        const size_t zb = (size_t)D * s->tw * 8, cap = 160 * 1024 - 4096;
+        size_t nw = zb ? cap / zb : 4;
+        k.stream_waves = (int)(nw < 1 ? 1 : (nw > 4 ? 4 : nw));
+        if (const char *e = getenv("KLHR_STREAM_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 4) k.stream_waves = v; }
+    }
     k.fit_waves = 1024;          // 256 CUs x 4 SIMDs, one fit wavefront each (KLHR_FIT_WAVES overrides: tuning aid)
     if (const char *e = getenv("KLHR_FIT_WAVES")) k.fit_waves = atoi(e);
     k.flags = (cfg->scale_dir_cov ? FLAG_SCALE_DIR_COV : 0) | (cfg->eigen_method_one ? FLAG_EIGEN_ONE : 0) |

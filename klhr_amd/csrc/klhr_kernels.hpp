@@ -69,6 +69,7 @@ struct KParams {
     double *fitbuf;              // per-chain fit records, SoA [F_NFIELDS][Cpad]
     unsigned int *qhead;         // [2][KLHR_NQ] heads of the fit sub-queues, one per 128-byte line
     int fit_waves;               // wavefronts of a fit launch (0: one per 64 chains)
+    int stream_waves;            // streaming kernel: wavefronts (tiles) per workgroup, sharing one LDS copy of the ziggurat tables
 };
 
 // per-chain fit record of the split pipeline, SoA: field f of chain c at fitbuf[f * Cpad + c]

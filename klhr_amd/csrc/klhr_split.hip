@@ -17,8 +17,9 @@ template <int MODEL>
 static void launch_split_model(const KParams &kp, int what, bool overrelaxed, int do_tail, int do_head, hipStream_t stream) {
     constexpr int V = KLHR_VARIANT;
     const unsigned tiles = (unsigned)((kp.C + 63) / 64);          // fit / probe kernels: 64 chains per wavefront
-    const unsigned stiles = (unsigned)(kp.Cpad / kp.tw);          // streaming kernel: one wavefront per tile of tw chains
-    const dim3 block(64);
+    const unsigned stiles = (unsigned)(kp.Cpad / kp.tw);          // streaming kernel: one wavefront per tile of tw chains,
+    const unsigned sgroups = (stiles + kp.stream_waves - 1) / kp.stream_waves;      // stream_waves tiles per workgroup
+    const dim3 block(64), sblock(64 * kp.stream_waves);
     // fit launches: at most `fit_waves` wavefronts (the resident capacity); chains beyond 64 per wavefront go through the queue
     const unsigned fitgrid = kp.fit_waves > 0 && (unsigned)kp.fit_waves < tiles ? (unsigned)kp.fit_waves : tiles;
     if (what == 1) {
@@ -28,14 +29,15 @@ static void launch_split_model(const KParams &kp, int what, bool overrelaxed, in
     } else if (what == 3) {
         hipLaunchKernelGGL((klhr_probe_kernel<MODEL, V>), dim3(tiles), block, 0, stream, kp);
     } else {
-        const size_t lds = ((size_t)kp.D * kp.tw + KLHR_ZTAB_DOUBLES) * sizeof(double);
-        if (overrelaxed) {
-            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)klhr_stream_kernel<MODEL, true, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((klhr_stream_kernel<MODEL, true, V>), dim3(stiles), block, lds, stream, kp, do_tail, do_head);
-        } else {
-            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)klhr_stream_kernel<MODEL, false, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((klhr_stream_kernel<MODEL, false, V>), dim3(stiles), block, lds, stream, kp, do_tail, do_head);
-        }
+        const size_t lds = ((size_t)kp.stream_waves * kp.D * kp.tw + KLHR_ZTAB_DOUBLES) * sizeof(double);
+#define KLHR_LAUNCH_STREAM(O, TW)                                                                                                      \
+    do {                                                                                                                               \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)klhr_stream_kernel<MODEL, O, V, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((klhr_stream_kernel<MODEL, O, V, TW>), dim3(sgroups), sblock, lds, stream, kp, do_tail, do_head);                \
+    } while (0)
+        if (kp.tw == 16) { if (overrelaxed) KLHR_LAUNCH_STREAM(true, 16); else KLHR_LAUNCH_STREAM(false, 16); }
+        else { if (overrelaxed) KLHR_LAUNCH_STREAM(true, 64); else KLHR_LAUNCH_STREAM(false, 64); }
+#undef KLHR_LAUNCH_STREAM
     }
 }
 

@@ -403,25 +403,49 @@ __global__ __launch_bounds__(64) void klhr_probe_kernel(const KParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// The streaming kernel.  lane = chain; a wavefront owns tile blockIdx.x (W = p.tw chains, W in {16, 32, 64}; lanes >= W idle)
-// of every state array: element i of chain (tile, lane) of a [C][D] array sits at (tile*D + i)*W + lane.  Narrow tiles put
-// more wavefronts — more loads in flight — on the machine when there are few chains; the kernel is bound by memory latency
-// and bandwidth, not by its arithmetic.
-// A row is walked CH elements at a time with all loads of a chunk issued before the first use.
-template <int CH, class T>
-__device__ __forceinline__ void st_load(const T *base, long long stride, int i0, int D, T (&r)[CH]) {
-#pragma unroll
-    for (int k = 0; k < CH; k++) { const int i = i0 + k < D ? i0 + k : D - 1; r[k] = base[(long long)i * stride]; }
+// The streaming kernel.  lane = chain; a wavefront owns tile blockIdx.x (W chains, W = 16 or 64; lanes >= W idle) of every
+// state array: element i of chain (tile, lane) of a [C][D] array sits at (tile*D + i)*W + lane.  Narrow tiles put more
+// wavefronts — more loads in flight — on the machine when there are few chains.
+// A row is walked CH elements at a time: all loads of a chunk are issued before the first use, whole chunks carry no bounds
+// checks (one base address per array and chunk, immediate offsets k*W*8), the D % CH remaining elements go one by one.
+template <int CH, class F>
+__device__ __forceinline__ void for_chunks(int D, F f) {
+    int i0 = 0;
+    for (; i0 + CH <= D; i0 += CH) f(std::integral_constant<int, CH>(), i0);
+    for (; i0 < D; ++i0) f(std::integral_constant<int, 1>(), i0);
 }
 constexpr int ST_CH = 8;          // passes over several arrays
-constexpr int ST_CH1 = 24;        // passes over one array
+constexpr int ST_CH1 = 16;        // passes over one or two arrays
+
+// Software-pipelined form: `load(buf, i0)` fills a register buffer with the chunk at i0, `compute(buf, i0)` consumes it.
+// The loads of chunk j+1 are issued before chunk j is computed (two buffers): a wavefront of this kernel has at most one
+// or two neighbours on its SIMD (the LDS column scratch bounds the occupancy), so it hides its own memory latency.
+template <int CH, template <int> class BUF, class L, class C>
+__device__ __forceinline__ void for_chunks_pipelined(int D, L load, C compute) {
+    BUF<CH> a, b;
+    int i0 = 0;
+    if (CH <= D) load(a, 0);
+    for (; i0 + 2 * CH <= D; i0 += 2 * CH) {
+        load(b, i0 + CH);
+        compute(a, i0);
+        if (i0 + 3 * CH <= D) load(a, i0 + 2 * CH);
+        compute(b, i0 + CH);
+    }
+    if (i0 + CH <= D) { compute(a, i0); i0 += CH; }
+    for (; i0 < D; ++i0) { BUF<1> r; load(r, i0); compute(r, i0); }
+}
+template <int N> struct Buf1 { static constexpr int n = N; double v[N]; };
+template <int N> struct Buf2 { static constexpr int n = N; double v[N], q[N]; };
+template <int N> struct BufT1 { static constexpr int n = N; double th[N], rr[N], mm[N], vv[N], mn[N]; };
+template <int N> struct BufDir { static constexpr int n = N; double e0[N], e1[N], e2[N], cv[N], th[N]; int rk[N]; };
 
 #pragma clang fp contract(off)      // NumPy's element-wise roundings and summation orders (bit-exact pieces)
 
 // onlinepca.py:13-26 for the chain of this lane.  u = theta - mean in Z (LDS column of the lane, stride W), V = the tile's
 // pca_v rows.  Per component: sums (s, u.v) -> v' = w v + (1-w) u (u.v)/(|v|+tol), sums on v' -> u -= (u.v') v'/(|v'|^2+tol);
 // the deflation pass of component j also gathers the first sums of component j+1.
-__device__ inline void split_pca_update(const KParams &p, double *V, long long n_new, double *Z, int W) {
+template <int W>
+__device__ inline void split_pca_update(const KParams &p, double *V, long long n_new, double *Z) {
     const int D = p.D, K = p.J;
     const long long lim = n_new < K ? n_new : K;
     const long long vs = (long long)K * W;
@@ -436,43 +460,51 @@ __device__ inline void split_pca_update(const KParams &p, double *V, long long n
             const double w = ((double)(n_new - 1) - p.l) / (double)n_new;
             if (!have_sums) {
                 s = 0; udv = 0;
-                for (int i0 = 0; i0 < D; i0 += ST_CH1) {
-                    double vr[ST_CH1];
-                    st_load<ST_CH1>(Vc, vs, i0, D, vr);
+                for_chunks_pipelined<ST_CH1, Buf1>(D,
+                    [&](auto &b, int i0) {
 #pragma unroll
-                    for (int k = 0; k < ST_CH1; k++) if (i0 + k < D) { s += vr[k] * vr[k]; udv += Z[(i0 + k) * W] * vr[k]; }
-                }
+                        for (int k = 0; k < b.n; k++) b.v[k] = Vc[(i0 + k) * vs];
+                    },
+                    [&](auto &b, int i0) {
+#pragma unroll
+                        for (int k = 0; k < b.n; k++) { s += b.v[k] * b.v[k]; udv += Z[(i0 + k) * W] * b.v[k]; }
+                    });
             }
             const double nv = sqrt(s);
             double s2 = 0, udv2 = 0;
-            for (int i0 = 0; i0 < D; i0 += ST_CH1) {
-                double vr[ST_CH1];
-                st_load<ST_CH1>(Vc, vs, i0, D, vr);
+            for_chunks_pipelined<ST_CH1, Buf1>(D,
+                [&](auto &b, int i0) {
 #pragma unroll
-                for (int k = 0; k < ST_CH1; k++) if (i0 + k < D) {
-                    const double z = Z[(i0 + k) * W];
-                    const double vn = w * vr[k] + (1 - w) * z * udv / (nv + PCA_TOL);
-                    Vc[(i0 + k) * vs] = vn;
-                    s2 += vn * vn; udv2 += z * vn;
-                }
-            }
+                    for (int k = 0; k < b.n; k++) b.v[k] = Vc[(i0 + k) * vs];
+                },
+                [&](auto &b, int i0) {
+#pragma unroll
+                    for (int k = 0; k < b.n; k++) {
+                        const double z = Z[(i0 + k) * W];
+                        const double vn = w * b.v[k] + (1 - w) * z * udv / (nv + PCA_TOL);
+                        Vc[(i0 + k) * vs] = vn;
+                        s2 += vn * vn; udv2 += z * vn;
+                    }
+                });
             have_sums = false;
             if (col + 1 < lim) {          // (the deflation after the last component is never read: onlinepca.py:24-25)
                 const double nv2 = sqrt(s2);
                 const bool next_sums = col + 1 != n_new - 1;       // the next component is updated, not assigned
                 const double *Vn = V + (long long)(col + 1) * W;
                 s = 0; udv = 0;
-                for (int i0 = 0; i0 < D; i0 += ST_CH) {
-                    double vr[ST_CH], vq[ST_CH];
-                    st_load<ST_CH>(Vc, vs, i0, D, vr);
-                    if (next_sums) st_load<ST_CH>(Vn, vs, i0, D, vq);
+                for_chunks_pipelined<ST_CH, Buf2>(D,
+                    [&](auto &b, int i0) {
 #pragma unroll
-                    for (int k = 0; k < ST_CH; k++) if (i0 + k < D) {
-                        const double z = Z[(i0 + k) * W] - udv2 * vr[k] / (nv2 * nv2 + PCA_TOL);
-                        Z[(i0 + k) * W] = z;
-                        if (next_sums) { s += vq[k] * vq[k]; udv += z * vq[k]; }
-                    }
-                }
+                        for (int k = 0; k < b.n; k++) { b.v[k] = Vc[(i0 + k) * vs]; b.q[k] = next_sums ? Vn[(i0 + k) * vs] : 0.0; }
+                    },
+                    [&](auto &b, int i0) {
+#pragma unroll
+                        for (int k = 0; k < b.n; k++) {
+                            const double z = Z[(i0 + k) * W] - udv2 * b.v[k] / (nv2 * nv2 + PCA_TOL);
+                            Z[(i0 + k) * W] = z;
+                            if (next_sums) { s += b.q[k] * b.q[k]; udv += z * b.q[k]; }
+                        }
+                    });
                 have_sums = next_sums;
             }
         }
@@ -480,7 +512,8 @@ __device__ inline void split_pca_update(const KParams &p, double *V, long long n
 }
 
 // klhr_sinh.py:268-280 (+ the rank permutation multivariate_normal's SVD applies to the following windows' normals)
-__device__ inline void split_close_window(const KParams &p, long long c, long long tb, long long tbe, long long tbv, long long omN, double *Z, int W) {
+template <int W>
+__device__ inline void split_close_window(const KParams &p, long long c, long long tb, long long tbe, long long tbv, long long omN, double *Z) {
     const int D = p.D, K = p.J, nc = p.ncol;
     for (int i = 0; i < D; i++) {
         const long long e = tb + (long long)i * W;
@@ -536,29 +569,51 @@ __device__ __forceinline__ double grad_elem(const KParams &p, int i, double x, d
     else return -x;
 }
 
-template <int MODEL, bool OVERRELAX, int VARIANT>
-__global__ __launch_bounds__(64) void klhr_stream_kernel(const KParams p, const int do_tail, const int do_head) {
-    extern __shared__ double lds[];            // [D][W] column scratch (normals, then theta - mean), then the ziggurat tables
-    const int lane = threadIdx.x & 63;
-    const int W = p.tw;
-    const long long c = (long long)blockIdx.x * W + lane;
+// line sums of (theta_i, r_i) for coordinate i (r still unnormalised): A, B', C', max|a|, max|r| (a, r scaled by 1/s_i for
+// ill-normal; the maxima by 1/s_i^2, since |g_i| = |x_i| / s_i^2); the funnel's coordinate 0 (v) is kept aside
+template <int MODEL>
+__device__ __forceinline__ void line_accumulate(const KParams &p, int i, double th, double r, LineStat &st, double &Bs, double &Cs, double &m1) {
+    double a = th, rs = r;
+    if constexpr (MODEL == MODEL_ILL_NORMAL) { const double is = p.md.aux[i]; a = a * is; rs = rs * is; }
+    if (MODEL == MODEL_FUNNEL && i == 0) { st.v0 = a; st.r0 = r; }
+    else {
+        st.A = fma(a, a, st.A); Bs = fma(a, rs, Bs); Cs = fma(rs, rs, Cs);
+        if constexpr (MODEL == MODEL_ILL_NORMAL) { const double is = p.md.aux[i]; a = a * is; rs = rs * is; }
+        st.m0 = fmax(st.m0, fabs(a)); m1 = fmax(m1, fabs(rs));
+        if (a != a || rs != rs) st.m0 = NAN;
+    }
+}
+
+// A workgroup is p.stream_waves wavefronts (1-4), each with its own tile and its own LDS column block; the workgroup shares
+// one LDS copy of the ziggurat's WI / KI tables for the direction draw (4 KB; D = 100 x 64 lanes: three 51 200 B column
+// blocks + the tables = 157.7 KB, one workgroup per CU).
+template <int MODEL, bool OVERRELAX, int VARIANT, int W>
+__global__ __launch_bounds__(256) void klhr_stream_kernel(const KParams p, const int do_tail, const int do_head) {
+    extern __shared__ double lds[];            // [waves][D][W] column scratch (normals, then theta - mean), then the ziggurat tables
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long tile = (long long)blockIdx.x * p.stream_waves + wv;
+    const long long c = tile * W + lane;
     const int D = p.D, nc = p.ncol, K = p.J;
-    double *Z = lds + lane;
-    double *zwi = lds + (size_t)D * W;
+    double *Z = lds + (size_t)wv * D * W + lane;
+    double *zwi = lds + (size_t)p.stream_waves * D * W;
     uint64_t *zki = reinterpret_cast<uint64_t *>(zwi + 256);
     if (do_head && (p.phases & PH_DIR)) {
-        for (int i = lane; i < 256; i += 64) { zwi[i] = KLHR_ZIG_WI[i]; zki[i] = KLHR_ZIG_KI[i]; }
-        KLHR_WAVE_SYNC();
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) { zwi[i] = KLHR_ZIG_WI[i]; zki[i] = KLHR_ZIG_KI[i]; }
+        __syncthreads();
     }
-    if (blockIdx.x == 0) {      // empty the sub-queues of the two fit launches that follow
+    if (blockIdx.x == 0 && wv == 0) {      // empty the sub-queues of the two fit launches that follow
         p.qhead[lane * KLHR_QSTRIDE] = 0;
         p.qhead[(KLHR_NQ + lane) * KLHR_QSTRIDE] = 0;
     }
     if (lane >= W || c >= p.C) return;
-    const long long tb = (long long)blockIdx.x * D * W + lane;
-    const long long tbe = (long long)blockIdx.x * D * nc * W + lane;
-    const long long tbv = (long long)blockIdx.x * D * K * W + lane;
+    const long long tb = tile * D * W + lane;
+    const long long tbe = tile * D * nc * W + lane;
+    const long long tbv = tile * D * K * W + lane;
     const bool diag = (p.flags & FLAG_DIAG) != 0;
+    double *const theta = p.theta + tb, *const rho = p.d_rho + tb;
+#ifdef KLHR_STAMPS
+    unsigned long long stamp_t = __builtin_readcyclecounter(), st_state = 0, st_mh = 0, st_t1 = 0, st_pca = 0, st_norm = 0, st_dir = 0, st_fin = 0;
+#endif
 
     Pcg64 rng;
     rng.sh = p.rng[c * 4 + 0]; rng.sl = p.rng[c * 4 + 1]; rng.ih = p.rng[c * 4 + 2]; rng.il = p.rng[c * 4 + 3];
@@ -569,6 +624,7 @@ __global__ __launch_bounds__(64) void klhr_stream_kernel(const KParams p, const 
     int Kc = p.K;
     if (VARIANT == VAR_GAUSS) { sm_x = p.kstate[c * 4 + 0]; sm_cnt = p.kstate[c * 4 + 1]; Kc = (int)p.kstate[c * 4 + 2]; moved_f = p.kstate[c * 4 + 3]; }
 
+    KLHR_STAMP(st_state);
     // =================================================================== tail of iteration k (klhr_sinh.py:266-287)
     if (do_tail) {
         // grad_evals += nfev1 + 8 nfev2 of the fit that preceded this tail (klhr_sinh.py:188,200)
@@ -606,6 +662,7 @@ __global__ __launch_bounds__(64) void klhr_stream_kernel(const KParams p, const 
             acc += (ad - acc) / (double)draw;
             if (diag) { double *dd = p.d_diag + c * KLHR_NDIAG; dd[KLHR_D_ZP] = zp; dd[KLHR_D_R] = r; dd[KLHR_D_LOGU] = logu; dd[KLHR_D_ACCEPT] = a; }
         }
+        KLHR_STAMP(st_mh);
         bool closed = false;
         if (adapt && !(p.warmup < p.windowsize) && p.nclos > 0) {
             closed = draw == p.closures[cidx];
@@ -618,44 +675,48 @@ __global__ __launch_bounds__(64) void klhr_stream_kernel(const KParams p, const 
         // ---- pass T1: theta' = a (theta + zp rho) + (1 - a) theta; OnlineMoments(theta'); Z = theta' - mean
         double d2 = 0.0, ssq = 0.0;
         bool fin = true;
-        {
-            for (int i0 = 0; i0 < D; i0 += ST_CH) {
-                double th[ST_CH], rr[ST_CH], mm[ST_CH], vv[ST_CH], mn_[ST_CH];
-                st_load<ST_CH>(p.theta + tb, W, i0, D, th);
-                if (mh) st_load<ST_CH>(p.d_rho + tb, W, i0, D, rr);
-                if (upd) { st_load<ST_CH>(p.om_m + tb, W, i0, D, mm); st_load<ST_CH>(p.om_v + tb, W, i0, D, vv); st_load<ST_CH>(p.mean + tb, W, i0, D, mn_); }
+        double *const om_m = p.om_m + tb, *const om_v = p.om_v + tb;
+        const double *const mean = p.mean + tb;
+        for_chunks_pipelined<ST_CH, BufT1>(D,
+            [&](auto &b, int i0) {
 #pragma unroll
-                for (int k = 0; k < ST_CH; k++) {
+                for (int k = 0; k < b.n; k++) {
+                    b.th[k] = theta[(i0 + k) * W];
+                    b.rr[k] = mh ? rho[(i0 + k) * W] : 0.0;
+                    if (upd) { b.mm[k] = om_m[(i0 + k) * W]; b.vv[k] = om_v[(i0 + k) * W]; b.mn[k] = mean[(i0 + k) * W]; }
+                }
+            },
+            [&](auto &b, int i0) {
+#pragma unroll
+                for (int k = 0; k < b.n; k++) {
                     const int i = i0 + k;
-                    if (i < D) {
-                        double nx = th[k];
-                        if (mh) {
-                            const double rho = rr[k] / nn;
-                            const double thp = add_rn(mul_rn(zp, rho), th[k]);
-                            nx = add_rn(mul_rn(ad, thp), mul_rn(na, th[k]));     // a*thetap + (1-a)*theta
-                            if (VARIANT == VAR_GAUSS) d2 += (nx - th[k]) * (nx - th[k]);
-                            p.theta[tb + (long long)i * W] = nx;
-                        }
-                        if (!isfinite(nx)) fin = false;
-                        if (out) out[i] = nx;
-                        if (i > 0 || MODEL != MODEL_FUNNEL) ssq += nx * nx;
-                        if (upd) {
-                            double mi = mm[k], vi = vv[k];
-                            const double d = nx - mi;
-                            mi += d * w;
-                            vi += -vi * w + d * d * w * (1 - w);
-                            p.om_m[tb + (long long)i * W] = mi;
-                            p.om_v[tb + (long long)i * W] = vi;
-                            Z[i * W] = nx - mn_[k];
-                        }
+                    double nx = b.th[k];
+                    if (mh) {
+                        const double rho_i = b.rr[k] / nn;
+                        const double thp = add_rn(mul_rn(zp, rho_i), b.th[k]);
+                        nx = add_rn(mul_rn(ad, thp), mul_rn(na, b.th[k]));     // a*thetap + (1-a)*theta
+                        if (VARIANT == VAR_GAUSS) d2 += (nx - b.th[k]) * (nx - b.th[k]);
+                        theta[i * W] = nx;
+                    }
+                    if (!isfinite(nx)) fin = false;
+                    if (out) out[i] = nx;
+                    if (i > 0 || MODEL != MODEL_FUNNEL) ssq += nx * nx;
+                    if (upd) {
+                        double mi = b.mm[k], vi = b.vv[k];
+                        const double d = nx - mi;
+                        mi += d * w;
+                        vi += -vi * w + d * d * w * (1 - w);
+                        om_m[i * W] = mi;
+                        om_v[i * W] = vi;
+                        Z[i * W] = nx - b.mn[k];
                     }
                 }
-            }
-        }
+            });
         if (mh && VARIANT == VAR_GAUSS) moved_f = (sqrt(d2) > 0.0) ? 1.0 : 0.0;
         if (!fin) atomicOr(&p.status[c], 2);
+        KLHR_STAMP(st_t1);
         if (closed) {
-            split_close_window(p, c, tb, tbe, tbv, omN, Z, W);
+            split_close_window<W>(p, c, tb, tbe, tbv, omN, Z);
             omN = 0;
             pcan = 0;
             if (VARIANT == VAR_GAUSS) {      // klhr.py:212-214
@@ -670,33 +731,33 @@ __global__ __launch_bounds__(64) void klhr_stream_kernel(const KParams p, const 
                 const double clipb = VARIANT == VAR_GAUSS ? INFINITY : (VARIANT == VAR_SUB ? p.grad_clip : p.scale_clip);
                 double ev = 0.0, g0 = 0.0;
                 if constexpr (MODEL == MODEL_FUNNEL) {
-                    const double v = p.theta[tb];
+                    const double v = theta[0];
                     ev = exp(-v);
                     g0 = -v * (1.0 / 9.0) - 0.5 * (double)p.md.n + 0.5 * ev * ssq;
                 }
-                for (int i0 = 0; i0 < D; i0 += ST_CH) {
-                    double th[ST_CH], mm[ST_CH], vv[ST_CH];
-                    st_load<ST_CH>(p.theta + tb, W, i0, D, th);
-                    st_load<ST_CH>(p.omd_m + tb, W, i0, D, mm);
-                    st_load<ST_CH>(p.omd_v + tb, W, i0, D, vv);
+                double *const omd_m = p.omd_m + tb, *const omd_v = p.omd_v + tb;
+                for_chunks<ST_CH>(D, [&](auto n, int i0) {
+                    constexpr int N = decltype(n)::value;
+                    double th[N], mm[N], vv[N];
 #pragma unroll
-                    for (int k = 0; k < ST_CH; k++) {
+                    for (int k = 0; k < N; k++) { th[k] = theta[(i0 + k) * W]; mm[k] = omd_m[(i0 + k) * W]; vv[k] = omd_v[(i0 + k) * W]; }
+#pragma unroll
+                    for (int k = 0; k < N; k++) {
                         const int i = i0 + k;
-                        if (i < D) {
-                            const double x = clipc(grad_elem<MODEL>(p, i, th[k], ev, g0), clipb);
-                            double mi = mm[k], vi = vv[k];
-                            const double d = x - mi;
-                            mi += d * w;
-                            vi += -vi * w + d * d * w * (1 - w);
-                            p.omd_m[tb + (long long)i * W] = mi;
-                            p.omd_v[tb + (long long)i * W] = vi;
-                        }
+                        const double x = clipc(grad_elem<MODEL>(p, i, th[k], ev, g0), clipb);
+                        double mi = mm[k], vi = vv[k];
+                        const double d = x - mi;
+                        mi += d * w;
+                        vi += -vi * w + d * d * w * (1 - w);
+                        omd_m[i * W] = mi;
+                        omd_v[i * W] = vi;
                     }
-                }
+                });
             }
             pcan += 1;
-            split_pca_update(p, p.pca_v + tbv, pcan, Z, W);
+            split_pca_update<W>(p, p.pca_v + tbv, pcan, Z);
         }
+        KLHR_STAMP(st_pca);
     }
 
     // =================================================================== head of iteration k+1 (klhr_sinh.py:264-265)
@@ -707,7 +768,11 @@ __global__ __launch_bounds__(64) void klhr_stream_kernel(const KParams p, const 
         if (p.phases & PH_DIR) {
             // eigen_method_one: rng.choice() consumes one uniform BEFORE the D normals (klhr_sinh.py:207,212)
             const double u_choice = (p.flags & FLAG_EIGEN_ONE) ? pcg_next_double(rng) : 0.0;
-            for (int k = 0; k < D; k++) Z[k * W] = rng_std_normal_tab(rng, zwi, zki);
+            // (64 lanes: a lane in the ziggurat's slow branch parks while the others go on; 16 lanes: the slow branch is rare
+            //  enough per wavefront-draw — 18 % — that the plain loop is faster, measured 64 k vs 89 k cycles per 100 normals)
+            if constexpr (W >= 32) rng_std_normal_column(rng, Z, W, D, zwi, zki);
+            else { for (int k = 0; k < D; k++) Z[k * W] = rng_std_normal_tab(rng, zwi, zki); }
+            KLHR_STAMP(st_norm);
             const double *ev = p.eigvals + c * nc;
             double pj[4] = {0, 0, 0, 0};
             double sum = 0;
@@ -726,68 +791,53 @@ __global__ __launch_bounds__(64) void klhr_stream_kernel(const KParams p, const 
                 for (int j = 0; j < 4; j++) if (j < nc && cdf[j] / last <= u_choice) pick = j + 1;
                 if (pick >= nc) pick = nc - 1;
             }
+            // weights of the eigenvector columns in the direction's mean (klhr.py:150 weights by raw eigenvalues)
+            double wj[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) wj[j] = pick >= 0 ? (j == pick ? 1.0 : 0.0) : ((VARIANT == VAR_GAUSS || VARIANT == VAR_SLICE) ? (j < nc ? ev[j] : 0.0) : pj[j]);
             double n2 = 0;
-            for (int i0 = 0; i0 < D; i0 += ST_CH) {
-                double e0[ST_CH], e1[ST_CH], e2[ST_CH], cv[ST_CH], th[ST_CH];
-                int rk[ST_CH];
-                st_load<ST_CH>(p.eigvecs + tbe, (long long)nc * W, i0, D, e0);
-                if (nc > 1) st_load<ST_CH>(p.eigvecs + tbe + W, (long long)nc * W, i0, D, e1);
-                if (nc > 2) st_load<ST_CH>(p.eigvecs + tbe + 2 * W, (long long)nc * W, i0, D, e2);
-                st_load<ST_CH>(p.cov + tb, W, i0, D, cv);
-                st_load<ST_CH>(p.rank + tb, W, i0, D, rk);
-                st_load<ST_CH>(p.theta + tb, W, i0, D, th);
+            const double *const evec = p.eigvecs + tbe, *const cov = p.cov + tb;
+            const int *const rank = p.rank + tb;
+            const long long es = (long long)nc * W;
+            for_chunks_pipelined<ST_CH, BufDir>(D,
+                [&](auto &b, int i0) {
 #pragma unroll
-                for (int k = 0; k < ST_CH; k++) {
-                    const int i = i0 + k;
-                    if (i < D) {
-                        double m = 0;
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            if (j < nc) {
-                                const double e = j == 0 ? e0[k] : (j == 1 ? e1[k] : (j == 2 ? e2[k] : p.eigvecs[tbe + ((long long)i * nc + j) * W]));
-                                if (pick >= 0) { if (j == pick) m = e; }
-                                else m += ((VARIANT == VAR_GAUSS || VARIANT == VAR_SLICE) ? ev[j] : pj[j]) * e;      // klhr.py:150
-                            }
-                        }
-                        const double r = m + sqrt(cv[k]) * Z[rk[k] * W];
-                        n2 += (r + p.tol) * (r + p.tol);
-                        p.d_rho[tb + (long long)i * W] = r;
-                        // line sums on (theta, unnormalised r): scaled by 1/nn afterwards
-                        double a = th[k], rs = r;
-                        if constexpr (MODEL == MODEL_ILL_NORMAL) { const double is = p.md.aux[i]; a = a * is; rs = rs * is; }
-                        if (MODEL == MODEL_FUNNEL && i == 0) { st.v0 = a; st.r0 = r; }
-                        else {
-                            st.A = fma(a, a, st.A); Bs = fma(a, rs, Bs); Cs = fma(rs, rs, Cs);
-                            if constexpr (MODEL == MODEL_ILL_NORMAL) { const double is = p.md.aux[i]; a = a * is; rs = rs * is; }     // |g_i| = |x_i| / s_i^2
-                            st.m0 = fmax(st.m0, fabs(a)); m1 = fmax(m1, fabs(rs));
-                            if (a != a || rs != rs) st.m0 = NAN;
-                        }
+                    for (int k = 0; k < b.n; k++) {
+                        b.e0[k] = evec[(i0 + k) * es];
+                        b.e1[k] = nc > 1 ? evec[(i0 + k) * es + W] : 0.0;
+                        b.e2[k] = nc > 2 ? evec[(i0 + k) * es + 2 * W] : 0.0;
+                        b.cv[k] = cov[(i0 + k) * W]; b.rk[k] = rank[(i0 + k) * W]; b.th[k] = theta[(i0 + k) * W];
                     }
-                }
-            }
+                },
+                [&](auto &b, int i0) {
+#pragma unroll
+                    for (int k = 0; k < b.n; k++) {
+                        const int i = i0 + k;
+                        double m = 0;
+                        if (pick >= 0) m = pick == 0 ? b.e0[k] : (pick == 1 ? b.e1[k] : (pick == 2 ? b.e2[k] : evec[i * es + 3 * W]));
+                        else {
+                            m += wj[0] * b.e0[k];
+                            if (nc > 1) m += wj[1] * b.e1[k];
+                            if (nc > 2) m += wj[2] * b.e2[k];
+                            if (nc > 3) m += wj[3] * evec[i * es + 3 * W];
+                        }
+                        const double r = m + sqrt(b.cv[k]) * Z[b.rk[k] * W];
+                        n2 += (r + p.tol) * (r + p.tol);
+                        rho[i * W] = r;
+                        line_accumulate<MODEL>(p, i, b.th[k], r, st, Bs, Cs, m1);
+                    }
+                });
             nn = sqrt(n2);
         } else {
             // direction given in d_rho (klhr_fit / klhr_metropolis / probes of the C ABI): nn = 1
-            for (int i0 = 0; i0 < D; i0 += ST_CH) {
-                double rr[ST_CH], th[ST_CH];
-                st_load<ST_CH>(p.d_rho + tb, W, i0, D, rr);
-                st_load<ST_CH>(p.theta + tb, W, i0, D, th);
+            for_chunks<ST_CH>(D, [&](auto n, int i0) {
+                constexpr int N = decltype(n)::value;
+                double rr[N], th[N];
 #pragma unroll
-                for (int k = 0; k < ST_CH; k++) {
-                    const int i = i0 + k;
-                    if (i < D) {
-                        double a = th[k], rs = rr[k];
-                        if constexpr (MODEL == MODEL_ILL_NORMAL) { const double is = p.md.aux[i]; a = a * is; rs = rs * is; }
-                        if (MODEL == MODEL_FUNNEL && i == 0) { st.v0 = a; st.r0 = rs; }
-                        else {
-                            st.A = fma(a, a, st.A); Bs = fma(a, rs, Bs); Cs = fma(rs, rs, Cs);
-                            if constexpr (MODEL == MODEL_ILL_NORMAL) { const double is = p.md.aux[i]; a = a * is; rs = rs * is; }
-                            st.m0 = fmax(st.m0, fabs(a)); m1 = fmax(m1, fabs(rs));
-                            if (a != a || rs != rs) st.m0 = NAN;
-                        }
-                    }
-                }
-            }
+                for (int k = 0; k < N; k++) { rr[k] = rho[(i0 + k) * W]; th[k] = theta[(i0 + k) * W]; }
+#pragma unroll
+                for (int k = 0; k < N; k++) line_accumulate<MODEL>(p, i0 + k, th[k], rr[k], st, Bs, Cs, m1);
+            });
         }
         {
             const double inv = 1.0 / nn;
@@ -796,7 +846,7 @@ __global__ __launch_bounds__(64) void klhr_stream_kernel(const KParams p, const 
         }
         if (diag && (p.phases & PH_DIR)) {
             // diagnostics / klhr_random_direction: leave the normalised direction itself in d_rho (nn becomes 1)
-            for (int i = 0; i < D; i++) p.d_rho[tb + (long long)i * W] = p.d_rho[tb + (long long)i * W] / nn;
+            for (int i = 0; i < D; i++) rho[i * W] = rho[i * W] / nn;
             nn = 1.0;
         }
         KLHR_FB(p, F_S0, c) = st.v0; KLHR_FB(p, F_S1, c) = st.r0; KLHR_FB(p, F_S2, c) = st.A; KLHR_FB(p, F_S3, c) = st.B;
@@ -814,6 +864,7 @@ __global__ __launch_bounds__(64) void klhr_stream_kernel(const KParams p, const 
             }
             KLHR_FB(p, F_N2, c) = n2v; KLHR_FB(p, F_N3, c) = n3v;
         }
+        KLHR_STAMP(st_dir);
     }
 
     // ---- store the per-chain scalars
@@ -821,6 +872,14 @@ __global__ __launch_bounds__(64) void klhr_stream_kernel(const KParams p, const 
     p.counters[c * 4 + 0] = draw; p.counters[c * 4 + 1] = omN; p.counters[c * 4 + 2] = pcan; p.counters[c * 4 + 3] = cidx;
     p.acc[c] = acc;
     if (VARIANT == VAR_GAUSS) { p.kstate[c * 4 + 0] = sm_x; p.kstate[c * 4 + 1] = sm_cnt; p.kstate[c * 4 + 2] = (double)Kc; p.kstate[c * 4 + 3] = moved_f; }
+#ifdef KLHR_STAMPS
+    KLHR_STAMP(st_fin);
+    if (lane == 0) {      // diagnostic build: cycle totals of this launch's phases, accumulated in the tile's first diag row
+        double *ds = p.d_diag + c * KLHR_NDIAG;
+        ds[0] += (double)st_state; ds[1] += (double)st_mh; ds[2] += (double)st_t1; ds[3] += (double)st_pca; ds[4] += (double)st_norm;
+        ds[5] += (double)st_dir; ds[6] += (double)st_fin; ds[7] += 1.0;
+    }
+#endif
 }
 #pragma clang fp contract(fast)
 

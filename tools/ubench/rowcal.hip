@@ -23,6 +23,22 @@ __global__ void coalesced_read(const double2 *a, double *out, long n) {
     for (; i < n; i += (long)gridDim.x * blockDim.x) { double2 v = a[i]; s += v.x + v.y; }
     if (s == 1234.5) out[0] = s;
 }
+// The split pipeline's pattern (klhr_split.hpp): a wavefront walks the D rows of its tile, row i = W lanes x 8 bytes
+// contiguous (512 B at W = 64, 128 B at W = 16), tiles D*W*8 bytes apart; each byte touched once.
+__global__ void tile_read(const double *a, double *out, long tiles, int D, int W) {
+    const long t = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (t >= tiles || lane >= W) return;
+    double s = 0;
+    for (int i = 0; i < D; i++) s += a[(t * D + i) * W + lane];
+    if (s == 1234.5) out[0] = s;
+}
+__global__ void tile_write(double *a, long tiles, int D, int W, double v) {
+    const long t = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (t >= tiles || lane >= W) return;
+    for (int i = 0; i < D; i++) a[(t * D + i) * W + lane] = v + i;
+}
 int main(int argc, char **argv) {
     const int D = argc > 1 ? atoi(argv[1]) : 10;
     const long rows = 1L << 25;                       // 33.5 M rows * D * 8 B = 2.7 GB at D = 10
@@ -36,6 +52,12 @@ int main(int argc, char **argv) {
     hipDeviceSynchronize();
     hipLaunchKernelGGL(coalesced_read, dim3(4096), dim3(256), 0, 0, (const double2 *)a, out, rows * D / 2);
     hipDeviceSynchronize();
+    for (int W = 64; W >= 16; W /= 4) {
+        hipLaunchKernelGGL(tile_write, dim3(rows / W), dim3(64), 0, 0, a, rows / W, D, W, 2.0);
+        hipDeviceSynchronize();
+        hipLaunchKernelGGL(tile_read, dim3(rows / W), dim3(64), 0, 0, a, out, rows / W, D, W);
+        hipDeviceSynchronize();
+    }
     printf("bytes per kernel: %ld (rows %ld, D %d)\n", rows * D * 8, rows, D);
     return 0;
 }
