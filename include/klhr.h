@@ -89,8 +89,10 @@ KLHR_API int klhr_device_count(void);                          /* visible HIP de
 KLHR_API int klhr_dim(const klhr_sampler *s);                  /* replaces BSModel.dim() (bsmodel.py:39-40) */
 KLHR_API int klhr_chains(const klhr_sampler *s);
 KLHR_API int klhr_sync(klhr_sampler *s);                       /* wait for the handle's stream */
-/* which hot-path kernel this handle launches: 0 = octet-per-chain (klhr_iter_kernel), 1 = lane-per-chain
- * (klhr_lane_kernel, model dimension <= 26).  Results are the same; only the mapping to the machine differs. */
+/* which hot-path kernels this handle launches: 0 = octet-per-chain (klhr_iter_kernel), 1 = lane-per-chain
+ * (klhr_lane_kernel, model dimension <= 26), 2 = split-phase pipeline (klhr_stream_kernel + klhr_fit1_kernel +
+ * klhr_fit2_kernel: funnel / ill-normal / normal above dimension 26).  Results agree within the stated tolerances;
+ * only the mapping to the machine differs.  KLHR_KERNEL = octet | lane | mono | split in the environment overrides. */
 KLHR_API int klhr_kernel_variant(const klhr_sampler *s);
 
 /* ---- seeding / initialisation --------------------------------------------------------------- */
@@ -192,6 +194,12 @@ KLHR_API int klhr_pool_apply_full(klhr_sampler *s, const double *mean, const dou
 /* HIP-event time (ms) of the kernels launched by the most recent klhr_step on the handle's stream,
  * and the number of kernel launches it made.                                                      */
 KLHR_API int klhr_last_step_timing(klhr_sampler *s, double *kernel_ms, int *n_launches);
+/* Per-kernel timing for the roofline of bench.py.  The split-phase pipeline (klhr_kernel_variant == 2) runs three kernels per
+ * iteration; with profiling enabled klhr_step runs its chains as one group and brackets every kernel with HIP events on the
+ * handle's stream.  klhr_last_kernel_times: mean duration (ms) and launch count of [streaming kernel, mode-search kernel,
+ * KL-fit kernel] over the most recent klhr_step (monolithic kernels: slot 0 = the hot kernel).                            */
+KLHR_API int klhr_set_kernel_profiling(klhr_sampler *s, int enable);
+KLHR_API int klhr_last_kernel_times(klhr_sampler *s, double ms3[3], int n3[3]);
 
 #ifdef __cplusplus
 }

@@ -80,6 +80,8 @@ def lib():
         "klhr_pool_gram": (C.c_int, [vp, C.c_int64, C.c_int64, dp, C.c_size_t]),
         "klhr_pool_apply_full": (C.c_int, [vp, dp, dp, dp, dp]),
         "klhr_last_step_timing": (C.c_int, [vp, dp, C.POINTER(C.c_int)]),
+        "klhr_set_kernel_profiling": (C.c_int, [vp, C.c_int]),
+        "klhr_last_kernel_times": (C.c_int, [vp, dp, C.POINTER(C.c_int)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -94,7 +96,8 @@ EXPORTS = ["klhr_create", "klhr_destroy", "klhr_last_error", "klhr_abi_version",
            "klhr_seed", "klhr_seed_state", "klhr_window_closures", "klhr_step", "klhr_get_draws", "klhr_reserve_draws", "klhr_random_direction",
            "klhr_fit", "klhr_metropolis", "klhr_adapt", "klhr_set_slice", "klhr_slice_step", "klhr_kl_eval", "klhr_line_eval", "klhr_log_density_gradient",
            "klhr_primitives", "klhr_get_state", "klhr_set_state", "klhr_mh_seed", "klhr_mh_step", "klhr_pool_stats",
-           "klhr_pool_apply", "klhr_pool_gram", "klhr_pool_apply_full", "klhr_last_step_timing"]
+           "klhr_pool_apply", "klhr_pool_gram", "klhr_pool_apply_full", "klhr_last_step_timing", "klhr_set_kernel_profiling",
+           "klhr_last_kernel_times"]
 
 
 def device_count():
@@ -197,6 +200,20 @@ class Sampler:
         out = np.empty((n, self.C, self.D))
         self._ck(self._L.klhr_get_draws(self._h, dptr(out), int(first), n), "klhr_get_draws")
         return out
+
+    def kernel_profiling(self, on=True):
+        self._ck(self._L.klhr_set_kernel_profiling(self._h, int(bool(on))), "klhr_set_kernel_profiling")
+
+    def kernel_times(self):
+        """mean ms and launch counts of [stream, fit1, fit2] (split pipeline) or [hot kernel, 0, 0] over the last step()"""
+        ms = (C.c_double * 3)()
+        n = (C.c_int * 3)()
+        self._ck(self._L.klhr_last_kernel_times(self._h, ms, n), "klhr_last_kernel_times")
+        return [ms[i] for i in range(3)], [n[i] for i in range(3)]
+
+    def kernel_names(self):
+        return {0: ["klhr_iter_kernel"], 1: ["klhr_lane_kernel"], 2: ["klhr_stream_kernel", "klhr_fit1_kernel", "klhr_fit2_kernel"]}[
+            self._L.klhr_kernel_variant(self._h)]
 
     def timing(self):
         ms = C.c_double()

@@ -32,6 +32,25 @@ using namespace klhr;
 
 static thread_local std::string g_create_err;
 
+// HIP streams of a device, shared by every handle on it and kept for the life of the process.  HIP maps streams onto a few
+// hardware queues in creation order; streams created and destroyed per handle ended up, for later handles of a process,
+// with two chain groups on ONE hardware queue — their kernels then ran one after the other (measured: funnel-100 x 131 072
+// dropped from 1.39e8 to 0.90e8 it/s for the fourth sampler of a process).  Slot 0 is a handle's main stream, slots 1-3
+// carry the chain groups of the split pipeline.  Handles used at the same time share the streams: their work interleaves
+// in stream order, which is correct (every call forks and joins through events) if not concurrent.
+static hipStream_t g_stream_pool[64][4];
+static int stream_from_pool(int device, int slot, hipStream_t *out) {
+    if (device < 0 || device >= 64 || slot < 0 || slot >= 4) return -1;
+    if (!g_stream_pool[device][slot]) {
+        // all four at once, at the first handle of the process on this device: created later, after other work had gone
+        // through the device, the group streams shared hardware queues (funnel-100 x 131 072: 0.87e8 instead of 1.36e8 it/s)
+        for (int k = 0; k < 4; k++)
+            if (!g_stream_pool[device][k] && hipStreamCreateWithFlags(&g_stream_pool[device][k], hipStreamNonBlocking) != hipSuccess) return -1;
+    }
+    *out = g_stream_pool[device][slot];
+    return 0;
+}
+
 struct klhr_sampler {
     klhr_config cfg{};
     int C = 0, D = 0, ncol = 0, S = 0, S_lane = 0, n_model = 0;
@@ -39,6 +58,16 @@ struct klhr_sampler {
     bool split = false;          // split-phase pipeline (klhr_split.hpp): tiled state layout, three kernels per iteration
     size_t Cp = 0;               // chains the [C][D...] arrays are allocated for (whole tiles in the tiled layout)
     int tw = 64;                 // tile width of the tiled layout: chains per tile = lanes of a streaming wavefront in use
+    int groups = 1;              // klhr_step runs the chains as this many groups on separate HIP streams (split pipeline)
+    hipStream_t gstream[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t gev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr;
+    // per-kernel timing of the split pipeline (klhr_set_kernel_profiling): events between the kernels of every iteration
+    bool async_ok = false;       // klhr_step lets chains progress asynchronously (split pipeline)
+    unsigned int *h_pend = nullptr;      // pinned host copy of the groups' pending-chain counters
+    bool profile = false;
+    std::vector<hipEvent_t> pev;
+    int pev_used = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing_pending = false;
@@ -173,7 +202,11 @@ static int reset_state(klhr_sampler *s) {
     HIPCHECK(s, hipMemcpyAsync(k.cov, ones.data(), C * D * 8, hipMemcpyHostToDevice, s->stream));
     HIPCHECK(s, hipMemcpyAsync(k.rank, ident.data(), C * D * 4, hipMemcpyHostToDevice, s->stream));
     HIPCHECK(s, hipMemcpyAsync(k.eigvals, ones.data(), Cc * nc * 8, hipMemcpyHostToDevice, s->stream));
-    if (k.fitbuf) HIPCHECK(s, hipMemsetAsync(k.fitbuf, 0, (size_t)F_NFIELDS * C * 8, s->stream));
+    if (k.fitbuf) {
+        HIPCHECK(s, hipMemsetAsync(k.fitbuf, 0, (size_t)F_NFIELDS * C * 8, s->stream));
+        HIPCHECK(s, hipMemsetAsync(k.phase, 0, C * 4, s->stream));
+        HIPCHECK(s, hipMemsetAsync(k.togo, 0, C * 4, s->stream));
+    }
     HIPCHECK(s, hipMemsetAsync(k.theta, 0, C * D * 8, s->stream));
     HIPCHECK(s, hipMemsetAsync(k.mean, 0, C * D * 8, s->stream));
     HIPCHECK(s, hipMemsetAsync(k.eigvecs, 0, C * D * nc * 8, s->stream));
@@ -302,14 +335,38 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
     }
 #define TRY(x) do { int _rc = (x); if (_rc) return bail(_rc); } while (0)
     auto hip_try = [&](hipError_t e, const char *what) { if (e != hipSuccess) { s->err = std::string(what) + ": " + hipGetErrorString(e); return (int)KLHR_ERR_HIP; } return 0; };
-    TRY(hip_try(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking), "hipStreamCreate"));
+    if (stream_from_pool(cfg->device, 0, &s->stream)) { s->err = "hipStreamCreate failed"; return bail(KLHR_ERR_HIP); }
     TRY(hip_try(hipEventCreate(&s->ev0), "hipEventCreate"));
     TRY(hip_try(hipEventCreate(&s->ev1), "hipEventCreate"));
     KParams &k = s->kp;
     const size_t C = s->Cp, nc = s->ncol, J = cfg->J;
     k.C = s->C; k.D = D; k.S = S; k.ncol = s->ncol; k.J = cfg->J;
-    k.tiled = s->split ? 1 : 0; k.tw = s->tw; k.Cpad = (long long)s->Cp; k.draw_slot = 0;
-    if (s->split) { TRY(dalloc(s, &k.fitbuf, (size_t)F_NFIELDS * C)); TRY(dalloc(s, &k.qhead, 2 * 64 * 32)); }
+    k.tiled = s->split ? 1 : 0; k.tw = s->tw; k.Cpad = (long long)s->Cp; k.fstride = (long long)s->Cp; k.draw_slot = 0;
+    k.draw_stride = (long long)s->C * D;
+    if (s->split) {
+        TRY(dalloc(s, &k.fitbuf, (size_t)F_NFIELDS * C));
+        TRY(dalloc(s, &k.phase, C)); TRY(dalloc(s, &k.togo, C)); TRY(dalloc(s, &k.pend, 16));
+        { Opt *ob = nullptr; TRY(dalloc(s, &ob, C)); k.optbuf = ob; }
+        // Asynchronous chains in klhr_step (opt-in, KLHR_ASYNC=1; pass budgets KLHR_FIT_BUDGET1 / KLHR_FIT_BUDGET2).  Measured on
+        // funnel-100 x 131 072 and ill-normal-100 x 16 384: 1.33e8 vs 1.36e8 and 5.7e7 vs 6.1e7 it/s against the synchronous
+        // rounds — with the chains in 2-4 groups on their own streams the idle tail of one group's fit launch is already
+        // filled by the other groups' kernels, and the drain rounds at the end of a call cost more than the budget saves.
+        // A chain whose fits are persistently long bounds the call either way (it has to finish its own n draws).
+        k.async_mode = 0; k.budget1 = 12; k.budget2 = 28;
+        s->async_ok = false;
+        if (const char *e = getenv("KLHR_ASYNC")) s->async_ok = atoi(e) != 0;
+        if (const char *e = getenv("KLHR_FIT_BUDGET1")) { const int v = atoi(e); if (v >= 1) k.budget1 = v; }
+        if (const char *e = getenv("KLHR_FIT_BUDGET2")) { const int v = atoi(e); if (v >= 1) k.budget2 = v; }
+        // Chain groups of klhr_step: the streaming kernel is bound by memory, the fit kernels by the fp64 ALUs; with the chains
+        // in two groups on two HIP streams one group's fit overlaps the other group's streaming.  (Tuning aid: KLHR_GROUPS.)
+        s->groups = s->C >= 32768 ? 4 : (s->C >= 8192 ? 2 : 1);          // (measured: funnel-100 x 131 072: 1.0e8 / 1.2e8 / 1.4e8 it/s with 1 / 2 / 4 groups)
+        if (const char *e = getenv("KLHR_GROUPS")) { const int v = atoi(e); if (v >= 1 && v <= 4) s->groups = v; }
+        for (int g = 1; g < s->groups; g++) {
+            if (stream_from_pool(cfg->device, g, &s->gstream[g])) { s->err = "hipStreamCreate failed"; return bail(KLHR_ERR_HIP); }
+            TRY(hip_try(hipEventCreateWithFlags(&s->gev[g], hipEventDisableTiming), "hipEventCreate"));
+        }
+        TRY(hip_try(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming), "hipEventCreate"));
+    }
     {   // streaming kernel: as many tiles per workgroup (1-4 wavefronts) as fit 160 KB of LDS next to the shared 4 KB ziggurat
         // tables; small column blocks: 4 wavefronts per workgroup, several workgroups per CU
         const size_t zb = (size_t)D * s->tw * 8, cap = 160 * 1024 - 4096;
@@ -317,8 +374,6 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
         k.stream_waves = (int)(nw < 1 ? 1 : (nw > 4 ? 4 : nw));
         if (const char *e = getenv("KLHR_STREAM_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 4) k.stream_waves = v; }
     }
-    k.fit_waves = 1024;          // 256 CUs x 4 SIMDs, one fit wavefront each (KLHR_FIT_WAVES overrides: tuning aid)
-    if (const char *e = getenv("KLHR_FIT_WAVES")) k.fit_waves = atoi(e);
     k.flags = (cfg->scale_dir_cov ? FLAG_SCALE_DIR_COV : 0) | (cfg->eigen_method_one ? FLAG_EIGEN_ONE : 0) |
               (cfg->overrelaxed ? FLAG_OVERRELAXED : 0);
     k.K = cfg->K;
@@ -360,11 +415,17 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
 extern "C" void klhr_destroy(klhr_sampler *s) {
     if (!s) return;
     if (s->stream) (void)hipStreamSynchronize(s->stream);
+    for (hipEvent_t e : s->pev) (void)hipEventDestroy(e);
+    if (s->h_pend) (void)hipHostFree(s->h_pend);
     for (void *p : s->allocs) (void)hipFree(p);
     if (s->d_draws) (void)hipFree(s->d_draws);
+    for (int g = 1; g < 4; g++) {
+        if (s->gstream[g]) (void)hipStreamSynchronize(s->gstream[g]);          // (pooled streams are not destroyed)
+        if (s->gev[g]) (void)hipEventDestroy(s->gev[g]);
+    }
+    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
-    if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
 
@@ -387,11 +448,36 @@ static int launch_iter(klhr_sampler *s, const KParams &kp_in) {
     return 0;
 }
 
-static void launch_split(klhr_sampler *s, const KParams &kp, int what, int do_tail, int do_head) {
+static void launch_split(klhr_sampler *s, const KParams &kp, int what, int do_tail, int do_head, hipStream_t st = nullptr) {
     const bool o = s->cfg.overrelaxed != 0;
-    if (s->cfg.variant == 2) launch_split_v2(kp, s->cfg.model_id, what, o, do_tail, do_head, s->stream);
-    else if (s->cfg.variant == 1) launch_split_v1(kp, s->cfg.model_id, what, o, do_tail, do_head, s->stream);
-    else launch_split_v0(kp, s->cfg.model_id, what, o, do_tail, do_head, s->stream);
+    if (!st) st = s->stream;
+    if (s->cfg.variant == 2) launch_split_v2(kp, s->cfg.model_id, what, o, do_tail, do_head, st);
+    else if (s->cfg.variant == 1) launch_split_v1(kp, s->cfg.model_id, what, o, do_tail, do_head, st);
+    else launch_split_v0(kp, s->cfg.model_id, what, o, do_tail, do_head, st);
+}
+
+// The view of chain group g of G (whole tiles, contiguous) of a split-pipeline handle: every pointer advanced to the
+// group's first chain, C / Cpad the group's own.  Returns false for an empty group.
+static bool group_view(const klhr_sampler *s, const KParams &kp, int g, int G, KParams &out) {
+    out = kp;
+    if (G <= 1) return g == 0;
+    const long long tw = s->tw, tiles = (long long)s->Cp / tw, tg = (tiles + G - 1) / G;
+    const long long c0 = g * tg * tw;
+    if (c0 >= s->C) return false;
+    long long c1 = (g + 1) * tg * tw;
+    if (c1 > (long long)s->Cp) c1 = (long long)s->Cp;
+    const long long D = s->D, nc = s->ncol, J = s->cfg.J;
+    out.C = (int)((c1 < s->C ? c1 : s->C) - c0);
+    out.Cpad = c1 - c0;
+    out.theta += c0 * D; out.mean += c0 * D; out.cov += c0 * D; out.om_m += c0 * D; out.om_v += c0 * D; out.d_rho += c0 * D;
+    if (out.omd_m) { out.omd_m += c0 * D; out.omd_v += c0 * D; }
+    out.rank += c0 * D; out.eigvecs += c0 * D * nc; out.pca_v += c0 * D * J; out.eigvals += c0 * nc;
+    out.rng += c0 * 4; out.counters += c0 * 4; out.kstate += c0 * 4; out.d_eta += c0 * 4;
+    out.acc += c0; out.grad_evals += c0; out.status += c0; out.d_diag += c0 * KLHR_NDIAG;
+    out.fitbuf += c0;
+    if (out.draws) out.draws += c0 * D;
+    out.phase += c0; out.togo += c0; out.optbuf = reinterpret_cast<Opt *>(out.optbuf) + c0; out.pend += g;
+    return true;
 }
 
 static int ensure_draws(klhr_sampler *s, int64_t n_iters) {
@@ -419,23 +505,102 @@ static int run_phases(klhr_sampler *s, int phases, int64_t n_iters, int record_d
         // head of k (direction, line sums, the fit's normals)] -> mode-search kernel -> KL-fit kernel; one last stream launch
         // runs the tail of the final iteration.  Everything is enqueued on the handle's stream without host synchronisation.
         const int tailp = phases & (PH_MH | PH_ADAPT | PH_FIT), headp = phases & (PH_DIR | PH_FIT | PH_MH | PH_KL | PH_LINE);      // (a tail after a fit also books its evaluation counts)
+        // whole draws without diagnostics run as chain groups on their own streams (fork / join through events);
+        // per-kernel profiling runs one group so that the kernels of an iteration follow each other on one stream
+        const int G = (phases == PH_ALL && !record_diag && !s->profile) ? s->groups : 1;
+        const bool prof = s->profile && phases == PH_ALL;
+        const bool async = phases == PH_ALL && !record_diag && !s->profile && s->async_ok;
+        if (prof) {
+            const size_t need = (size_t)(n_iters + 1) * 4;
+            while (s->pev.size() < need) { hipEvent_t e; HIPCHECK(s, hipEventCreate(&e)); s->pev.push_back(e); }
+            s->pev_used = 0;
+        }
+        auto mark = [&](int slot) -> int { if (prof) { HIPCHECK(s, hipEventRecord(s->pev[slot], s->stream)); s->pev_used = slot + 1; } return 0; };
         HIPCHECK(s, hipEventRecord(s->ev0, s->stream));
+        if (G > 1) {
+            HIPCHECK(s, hipEventRecord(s->ev_fork, s->stream));
+            for (int g = 1; g < G; g++) HIPCHECK(s, hipStreamWaitEvent(s->gstream[g], s->ev_fork, 0));
+        }
+        if (async) {
+            // Asynchronous chains: n_iters + 1 rounds of [streaming kernel, mode search, KL fit]; every chain takes part in a
+            // launch according to its own phase, fits are cut at their pass budget and resumed in the next round.  Then drain
+            // rounds until no chain has work left (a chain loses one round per resumed fit: a few rounds, checked on the host).
+            if (!s->h_pend) HIPCHECK(s, hipHostMalloc((void **)&s->h_pend, 16 * sizeof(unsigned int), 0));
+            KParams kp0 = s->kp;
+            kp0.phases = phases;
+            kp0.n_iters = (int)n_iters;
+            kp0.async_mode = 1;
+            kp0.draws = record_draws ? s->d_draws : nullptr;
+            KParams kpg[4];
+            bool have[4] = {false, false, false, false};
+            for (int g = 0; g < G; g++) {
+                have[g] = group_view(s, kp0, g, G, kpg[g]);
+                if (!have[g]) continue;
+                hipStream_t st = g == 0 ? s->stream : s->gstream[g];
+                HIPCHECK(s, hipMemsetD32Async((hipDeviceptr_t)kpg[g].togo, (int)n_iters, (size_t)kpg[g].C, st));
+            }
+            auto round = [&](int g) {
+                hipStream_t st = g == 0 ? s->stream : s->gstream[g];
+                launch_split(s, kpg[g], 0, 1, 1, st);
+                launch_split(s, kpg[g], 1, 0, 0, st);
+                launch_split(s, kpg[g], 2, 0, 0, st);
+            };
+            for (int64_t it = 0; it <= n_iters; it++) {
+                for (int g = 0; g < G; g++) if (have[g]) round(g);
+                HIPCHECK(s, hipGetLastError());
+            }
+            bool todo[4] = {have[0], have[1], have[2], have[3]};
+            for (int guard = 0; guard < 100000; guard++) {
+                bool any = false;
+                for (int g = 0; g < G; g++) {
+                    if (!todo[g]) continue;
+                    any = true;
+                    hipStream_t st = g == 0 ? s->stream : s->gstream[g];
+                    HIPCHECK(s, hipMemsetAsync(kpg[g].pend, 0, sizeof(unsigned int), st));
+                    round(g);
+                    HIPCHECK(s, hipMemcpyAsync(&s->h_pend[g], kpg[g].pend, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+                }
+                if (!any) break;
+                for (int g = 0; g < G; g++) {
+                    if (!todo[g]) continue;
+                    HIPCHECK(s, hipStreamSynchronize(g == 0 ? s->stream : s->gstream[g]));
+                    if (s->h_pend[g] == 0) todo[g] = false;
+                }
+            }
+        } else
         for (int64_t it = 0; it <= n_iters; it++) {
-            KParams kp = s->kp;
-            kp.phases = phases;
-            kp.n_iters = 1;
-            if (record_diag) kp.flags |= FLAG_DIAG;
+            KParams kp0 = s->kp;
+            kp0.phases = phases;
+            kp0.n_iters = 1;
+            kp0.async_mode = 0;
+            if (record_diag) kp0.flags |= FLAG_DIAG;
             const int do_tail = it > 0 && tailp, do_head = it < n_iters && headp;
-            kp.draws = (record_draws && do_tail) ? s->d_draws : nullptr;
-            kp.draw_slot = (int)(it - 1);
-            if (do_tail || do_head) launch_split(s, kp, 0, do_tail, do_head);
-            if (it < n_iters && (phases & PH_FIT)) { launch_split(s, kp, 1, 0, 0); launch_split(s, kp, 2, 0, 0); }
-            if (it < n_iters && (phases & (PH_KL | PH_LINE))) {
-                const char *rep = getenv("KLHR_PROBE_REPEAT");
-                kp.n_iters = rep ? atoi(rep) : 1;
-                launch_split(s, kp, 3, 0, 0);
+            kp0.draws = (record_draws && do_tail) ? s->d_draws : nullptr;
+            kp0.draw_slot = (int)(it - 1);
+            for (int g = 0; g < G; g++) {
+                KParams kp;
+                if (!group_view(s, kp0, g, G, kp)) continue;
+                hipStream_t st = g == 0 ? s->stream : s->gstream[g];
+                if (mark((int)it * 4 + 0)) return KLHR_ERR_HIP;
+                if (do_tail || do_head) launch_split(s, kp, 0, do_tail, do_head, st);
+                if (mark((int)it * 4 + 1)) return KLHR_ERR_HIP;
+                if (it < n_iters && (phases & PH_FIT)) {
+                    launch_split(s, kp, 1, 0, 0, st);
+                    if (mark((int)it * 4 + 2)) return KLHR_ERR_HIP;
+                    launch_split(s, kp, 2, 0, 0, st);
+                    if (mark((int)it * 4 + 3)) return KLHR_ERR_HIP;
+                }
+                if (it < n_iters && (phases & (PH_KL | PH_LINE))) {
+                    const char *rep = getenv("KLHR_PROBE_REPEAT");
+                    kp.n_iters = rep ? atoi(rep) : 1;
+                    launch_split(s, kp, 3, 0, 0, st);
+                }
             }
             HIPCHECK(s, hipGetLastError());
+        }
+        for (int g = 1; g < G; g++) {
+            HIPCHECK(s, hipEventRecord(s->gev[g], s->gstream[g]));
+            HIPCHECK(s, hipStreamWaitEvent(s->stream, s->gev[g], 0));
         }
         HIPCHECK(s, hipEventRecord(s->ev1, s->stream));
         s->timing_pending = true;
@@ -492,6 +657,39 @@ extern "C" int klhr_last_step_timing(klhr_sampler *s, double *kernel_ms, int *n_
     }
     if (kernel_ms) *kernel_ms = s->last_ms;
     if (n_launches) *n_launches = s->last_launches;
+    return KLHR_OK;
+}
+
+// Per-kernel timing (split pipeline): with profiling on, klhr_step runs its chains as ONE group and brackets every kernel
+// with HIP events on the handle's stream; klhr_last_kernel_times returns the mean duration (ms) and the launch count of
+// [streaming kernel, mode-search kernel, KL-fit kernel] over the most recent klhr_step.  Monolithic kernels: slot 0 only.
+extern "C" int klhr_set_kernel_profiling(klhr_sampler *s, int enable) {
+    if (!s) return KLHR_ERR_ARG;
+    s->profile = enable != 0;
+    return KLHR_OK;
+}
+extern "C" int klhr_last_kernel_times(klhr_sampler *s, double ms3[3], int n3[3]) {
+    if (!s || !ms3 || !n3) return KLHR_ERR_ARG;
+    for (int k = 0; k < 3; k++) { ms3[k] = 0; n3[k] = 0; }
+    if (!s->split) {
+        double ms = 0; int nl = 0;
+        int rc = klhr_last_step_timing(s, &ms, &nl);
+        if (rc) return rc;
+        ms3[0] = nl ? ms / nl : 0; n3[0] = nl;
+        return KLHR_OK;
+    }
+    if (s->pev_used < 4) return KLHR_OK;
+    HIPCHECK(s, hipStreamSynchronize(s->stream));
+    double tot[3] = {0, 0, 0};
+    const int iters = s->pev_used / 4;
+    for (int it = 0; it < iters; it++)
+        for (int k = 0; k < 3; k++) {
+            float ms = 0;
+            if (it * 4 + k + 1 >= s->pev_used) break;
+            HIPCHECK(s, hipEventElapsedTime(&ms, s->pev[it * 4 + k], s->pev[it * 4 + k + 1]));
+            tot[k] += ms; n3[k] += 1;
+        }
+    for (int k = 0; k < 3; k++) ms3[k] = n3[k] ? tot[k] / n3[k] : 0;
     return KLHR_OK;
 }
 

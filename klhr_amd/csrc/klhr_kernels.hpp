@@ -65,12 +65,26 @@ struct KParams {
     const long long *closures;   // device array of window-closure draw indices
     // split-phase pipeline (klhr_split.hpp): tiled = 1 -> every [C][D...] state array is stored [tile][coordinate][64 lanes]
     int tiled, tw, draw_slot;    // tw: tile width (chains per tile: 16, 32 or 64)
-    long long Cpad;              // chains rounded up to whole tiles of 64
-    double *fitbuf;              // per-chain fit records, SoA [F_NFIELDS][Cpad]
-    unsigned int *qhead;         // [2][KLHR_NQ] heads of the fit sub-queues, one per 128-byte line
-    int fit_waves;               // wavefronts of a fit launch (0: one per 64 chains)
+    long long Cpad;              // chains of this launch rounded up to whole tiles
+    long long fstride;           // field stride of fitbuf (the handle's padded chain count)
+    long long draw_stride;       // doubles between two recorded iterations in `draws` (handle's chains x D)
+    double *fitbuf;              // per-chain fit records, SoA [F_NFIELDS][fstride]
     int stream_waves;            // streaming kernel: wavefronts (tiles) per workgroup, sharing one LDS copy of the ziggurat tables
+    // asynchronous chains (klhr_step on the split pipeline): every chain advances through head -> mode search -> KL fit ->
+    // tail at its own pace.  A fit launch gives every chain at most `budget` objective passes; a chain that is not done keeps
+    // its optimiser state in optbuf and goes on in the next round, while the other chains of the launch move on.
+    int async_mode;              // 0: every launch processes every chain to completion (C-ABI pieces, diagnostics, profiling)
+    int budget1, budget2;        // passes per launch of the mode search / the KL fit in async mode
+    int *phase;                  // per chain: PHS_* below
+    void *optbuf;                // per chain: saved optimiser state (struct Opt) of a fit in progress
+    int *togo;                   // per chain: draws of this klhr_step call (n_iters of them) still to be completed;
+                                 // a recorded draw goes to slot n_iters - togo
+    unsigned int *pend;          // [1] chains that still have work after this streaming launch (async mode)
 };
+// phase of a chain between two launches (async mode)
+enum { PHS_HEAD = 0,             // needs the head of its next iteration (or is finished: draw == target)
+       PHS_FIT1 = 1, PHS_FIT1_RESUME = 11, PHS_FIT2 = 2, PHS_FIT2_RESUME = 12,
+       PHS_TAIL = 3 };           // its fit is complete: needs the tail (MH, adaptation, draw output)
 
 // per-chain fit record of the split pipeline, SoA: field f of chain c at fitbuf[f * Cpad + c]
 enum { F_S0 = 0, F_S1, F_S2, F_S3, F_S4, F_S5, F_S6, F_NN, F_X0, F_N2, F_N3, F_MODE, F_INIT1, F_PASS, F_NFEV1, F_NFEV2, F_NFIELDS };

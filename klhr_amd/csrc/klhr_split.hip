@@ -20,8 +20,7 @@ static void launch_split_model(const KParams &kp, int what, bool overrelaxed, in
     const unsigned stiles = (unsigned)(kp.Cpad / kp.tw);          // streaming kernel: one wavefront per tile of tw chains,
     const unsigned sgroups = (stiles + kp.stream_waves - 1) / kp.stream_waves;      // stream_waves tiles per workgroup
     const dim3 block(64), sblock(64 * kp.stream_waves);
-    // fit launches: at most `fit_waves` wavefronts (the resident capacity); chains beyond 64 per wavefront go through the queue
-    const unsigned fitgrid = kp.fit_waves > 0 && (unsigned)kp.fit_waves < tiles ? (unsigned)kp.fit_waves : tiles;
+    const unsigned fitgrid = tiles;
     if (what == 1) {
         hipLaunchKernelGGL((klhr_fit1_kernel<MODEL>), dim3(fitgrid), block, 0, stream, kp);
     } else if (what == 2) {

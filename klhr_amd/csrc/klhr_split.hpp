@@ -31,7 +31,7 @@ namespace klhr {
 // (per-chain fit record F_*: klhr_kernels.hpp)
 struct LineStat { double v0, r0, A, B, C, m0, m1; };
 
-#define KLHR_FB(p, f, c) (p).fitbuf[(long long)(f) * (p).Cpad + (c)]
+#define KLHR_FB(p, f, c) (p).fitbuf[(long long)(f) * (p).fstride + (c)]
 
 __device__ __forceinline__ LineStat load_stat(const KParams &p, long long c) {
     LineStat s;
@@ -201,83 +201,40 @@ __device__ __forceinline__ void split_eval_kl(const KParams &p, const LineStat &
     }
 }
 
-// ---- the fit queue.
-// A fit launch has `grid` wavefronts; wavefront w starts on chains 64w .. 64w+63 (no atomics).  Chains from 64*grid on
-// (launches with more chains than resident lanes) wait in KLHR_NQ sub-queues — contiguous ranges of chains, each with its own
-// head counter on its own 128-byte line, so that claims from different wavefronts mostly hit different L2 channels.  A lane
-// whose fit has converged asks for the next chain; the wavefront's leader claims for all askers with ONE atomic add on the
-// wavefront's current sub-queue, issued one pass AHEAD of its use (the evaluation + optimiser step of the pass hide the
-// atomic's latency).  A wavefront that finds a sub-queue exhausted moves to the next; after KLHR_NQ exhausted ones it stops
-// asking.  Which lane runs a chain has no influence on the chain's arithmetic.
-#define KLHR_NQ 64
-#define KLHR_QSTRIDE 32          // unsigned ints between two heads (128 bytes)
-struct FitQueue {
-    unsigned int *heads;         // this stage's KLHR_NQ heads
-    long long q0, L, C;          // first queued chain, chains per sub-queue, number of chains
-    int cur, seen_empty;         // wave-uniform: current sub-queue, consecutive exhausted sub-queues
-    // one pass: begin() issues the claim for the lanes in `want`; end() hands out the chains
-    unsigned long long m;
-    unsigned int basev;
-    int leader;
-};
-__device__ __forceinline__ void fq_init(FitQueue &q, unsigned int *heads, long long q0, int C, int wave) {
-    q.heads = heads; q.q0 = q0; q.C = C;
-    const long long rest = C > q0 ? C - q0 : 0;
-    q.L = (rest + KLHR_NQ - 1) / KLHR_NQ;
-    q.cur = wave % KLHR_NQ;
-    q.seen_empty = rest > 0 ? 0 : KLHR_NQ;
-    q.m = 0; q.basev = 0; q.leader = 0;
-}
-__device__ __forceinline__ void fq_begin(FitQueue &q, bool want, int lane) {
-    q.m = q.seen_empty >= KLHR_NQ ? 0ull : __ballot(want);
-    if (q.m) {
-        q.leader = __ffsll((long long)q.m) - 1;
-        if (lane == q.leader) q.basev = atomicAdd(q.heads + q.cur * KLHR_QSTRIDE, (unsigned int)__popcll(q.m));
-    }
-}
-// returns the chain for this lane (-1: none); lanes that asked and got none keep asking until every sub-queue is exhausted
-__device__ __forceinline__ long long fq_end(FitQueue &q, bool want, int lane, bool &exhausted) {
-    exhausted = q.seen_empty >= KLHR_NQ;
-    if (!q.m) return -1;
-    const unsigned int base = (unsigned int)__shfl((int)q.basev, q.leader);
-    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(q.m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)q.m, 0u));
-    const long long lo = q.q0 + (long long)q.cur * q.L;
-    long long hi = lo + q.L;
-    if (hi > q.C) hi = q.C;
-    const long long t = lo + (long long)base + rank;
-    const bool asked = (q.m >> lane) & 1ull;
-    if (lo + (long long)base + __popcll(q.m) >= hi) {          // this sub-queue is (now) exhausted: move on
-        q.cur = (q.cur + 1) % KLHR_NQ;
-        q.seen_empty += 1;
-    } else q.seen_empty = 0;
-    exhausted = q.seen_empty >= KLHR_NQ;
-    return (asked && want && t < hi) ? t : -1;
-}
-
 // ------------------------------------------------------------------------------------------------
-// Stage 1 of fit(): minimize(logp_grad_rho, x0, BFGS, gtol = 1e-5) (klhr_sinh.py:183-190), one task per lane.
+// The fit kernels: lane = chain (64 chains per wavefront, static).  In async mode (KParams::async_mode) a launch gives every
+// chain at most `budget` passes: a chain whose fit has not converged by then writes its optimiser state to optbuf and resumes
+// in the next round, so that a fit of 80 passes (line-search fallbacks; one chain in a few thousand) costs that chain three
+// rounds instead of costing every chain of the launch the wait.  Which round a pass runs in has no influence on its arithmetic.
+__device__ __forceinline__ void opt_save(const KParams &p, long long c, const Opt &o, int npass) {
+    Opt *dst = reinterpret_cast<Opt *>(p.optbuf) + c;
+    *dst = o;
+    KLHR_FB(p, F_PASS, c) = (double)npass;
+}
+__device__ __forceinline__ void opt_restore(const KParams &p, long long c, Opt &o) { o = *(reinterpret_cast<const Opt *>(p.optbuf) + c); }
+
+// Stage 1 of fit(): minimize(logp_grad_rho, x0, BFGS, gtol = 1e-5) (klhr_sinh.py:183-190)
 template <int MODEL>
 __global__ __launch_bounds__(64) void klhr_fit1_kernel(const KParams p) {
     const int lane = threadIdx.x & 63;
-    Opt o;
-    LineStat st = {0, 0, 0, 0, 0, 0, 0};
-    long long task = (long long)blockIdx.x * 64 + lane;
-    bool live = false, want = false, fresh = task < p.C;
-    int npass = 0, ltrips = 0;
+    const long long task = (long long)blockIdx.x * 64 + lane;
+    if (task >= p.C) return;
     const bool diag = (p.flags & FLAG_DIAG) != 0;
-    FitQueue q;
-    fq_init(q, p.qhead, (long long)gridDim.x * 64, p.C, blockIdx.x);
-    for (;;) {
-        fq_begin(q, want, lane);
-        if (fresh) {
-            fresh = false; live = true;
-            st = load_stat(p, task);
-            const double x0v[4] = {KLHR_FB(p, F_X0, task), 0, 0, 0};
-            if (diag) p.d_diag[task * KLHR_NDIAG + KLHR_D_X0] = x0v[0];
-            opt_begin(o, 1, x0v, 1e-5);
-            npass = 0; ltrips = 0;
-        }
-        bool finished = false;
+    int ph = p.async_mode ? p.phase[task] : PHS_FIT1;
+    if (ph != PHS_FIT1 && ph != PHS_FIT1_RESUME) return;
+    Opt o;
+    const LineStat st = load_stat(p, task);
+    int npass = 0;
+    if (ph == PHS_FIT1_RESUME) { opt_restore(p, task, o); npass = (int)KLHR_FB(p, F_PASS, task); }
+    else {
+        const double x0v[4] = {KLHR_FB(p, F_X0, task), 0, 0, 0};
+        if (diag) p.d_diag[task * KLHR_NDIAG + KLHR_D_X0] = x0v[0];
+        opt_begin(o, 1, x0v, 1e-5);
+    }
+    const int budget = p.async_mode ? p.budget1 : KLHR_MAX_PASSES;
+    bool live = true;
+    int ltrips = 0;
+    while (__any(live)) {
         if (live) {
             double f = 0, g[4] = {0, 0, 0, 0};
             if (opt_cache_hit(o)) { f = o.lf; g[0] = o.lg[0]; }
@@ -289,7 +246,8 @@ __global__ __launch_bounds__(64) void klhr_fit1_kernel(const KParams p) {
                 npass++;
             }
             opt_advance<false, 1>(o, f, g);
-            const bool capped = ++ltrips > KLHR_MAX_PASSES;
+            ++ltrips;
+            const bool capped = npass > KLHR_MAX_PASSES;            // safety valve (klhr_kernels.hpp)
             if (o.pc == PC_DONE || capped) {
                 double s = o.H[0];
                 s = (s > 0 ? 1.0 : 0.0) * 0.5 * log(s);
@@ -303,17 +261,16 @@ __global__ __launch_bounds__(64) void klhr_fit1_kernel(const KParams p) {
                     dd[KLHR_D_MODE] = o.xk[0]; dd[KLHR_D_HINV1] = o.H[0]; dd[KLHR_D_NFEV1] = o.nfev; dd[KLHR_D_NIT1] = o.k;
                     dd[KLHR_D_STATUS1] = o.status; dd[KLHR_D_FALLBACKS] = o.fallbacks;
                 }
+                ph = PHS_FIT2;
                 live = false;
-                finished = true;
+            } else if (ltrips >= budget) {
+                opt_save(p, task, o, npass);
+                ph = PHS_FIT1_RESUME;
+                live = false;
             }
         }
-        bool exhausted;
-        const long long nt = fq_end(q, want, lane, exhausted);
-        if (want && nt >= 0) { task = nt; fresh = true; want = false; }
-        if (finished) want = true;
-        if (exhausted) want = false;
-        if (!__any(live || fresh || want)) break;
     }
+    if (p.async_mode) p.phase[task] = ph;
 }
 
 // Stage 2 of fit(): minimize(KL, init, BFGS, gtol = 1e-3) (klhr_sinh.py:191-201; klhr.py:134-139; sub_klhr_sinh.py:184-192)
@@ -321,32 +278,31 @@ template <int MODEL, int VARIANT>
 __global__ __launch_bounds__(64) void klhr_fit2_kernel(const KParams p) {
     constexpr int N = VARIANT == VAR_GAUSS ? 2 : (VARIANT == VAR_SUB ? 3 : 4);
     const int lane = threadIdx.x & 63;
-    Opt o;
-    LineStat st = {0, 0, 0, 0, 0, 0, 0};
-    double nn = 1.0;
-    long long task = (long long)blockIdx.x * 64 + lane;
-    bool live = false, want = false, fresh = task < p.C;
-    int npass = 0, ltrips = 0;
+    const long long task = (long long)blockIdx.x * 64 + lane;
+    if (task >= p.C) return;
     const bool diag = (p.flags & FLAG_DIAG) != 0;
-    FitQueue q;
-    fq_init(q, p.qhead + KLHR_NQ * KLHR_QSTRIDE, (long long)gridDim.x * 64, p.C, blockIdx.x);
-    for (;;) {
-        fq_begin(q, want, lane);
-        if (fresh) {
-            fresh = false; live = true;
-            st = load_stat(p, task);
-            nn = KLHR_FB(p, F_NN, task);
-            const double init[4] = {KLHR_FB(p, F_MODE, task), KLHR_FB(p, F_INIT1, task),
-                                    VARIANT == VAR_GAUSS ? 0.0 : KLHR_FB(p, F_N2, task),
-                                    VARIANT == VAR_SINH ? KLHR_FB(p, F_N3, task) : 0.0};
-            if (diag) {
-                double *dd = p.d_diag + task * KLHR_NDIAG;
-                dd[KLHR_D_INIT0] = init[0]; dd[KLHR_D_INIT1] = init[1]; dd[KLHR_D_INIT2] = init[2]; dd[KLHR_D_INIT3] = init[3];
-            }
-            opt_begin(o, N, init, VARIANT == VAR_GAUSS ? 1e-5 : 1e-3);
-            npass = 0; ltrips = 0;
+    int ph = p.async_mode ? p.phase[task] : PHS_FIT2;
+    if (ph != PHS_FIT2 && ph != PHS_FIT2_RESUME) return;
+    Opt o;
+    const LineStat st = load_stat(p, task);
+    const double nn = KLHR_FB(p, F_NN, task);
+    int npass = 0, npass1 = 0;
+    if (ph == PHS_FIT2_RESUME) { opt_restore(p, task, o); npass = (int)KLHR_FB(p, F_PASS, task); }
+    else {
+        npass1 = (int)KLHR_FB(p, F_PASS, task);
+        const double init[4] = {KLHR_FB(p, F_MODE, task), KLHR_FB(p, F_INIT1, task),
+                                VARIANT == VAR_GAUSS ? 0.0 : KLHR_FB(p, F_N2, task),
+                                VARIANT == VAR_SINH ? KLHR_FB(p, F_N3, task) : 0.0};
+        if (diag) {
+            double *dd = p.d_diag + task * KLHR_NDIAG;
+            dd[KLHR_D_INIT0] = init[0]; dd[KLHR_D_INIT1] = init[1]; dd[KLHR_D_INIT2] = init[2]; dd[KLHR_D_INIT3] = init[3];
         }
-        bool finished = false;
+        opt_begin(o, N, init, VARIANT == VAR_GAUSS ? 1e-5 : 1e-3);
+    }
+    const int budget = p.async_mode ? p.budget2 : KLHR_MAX_PASSES;
+    bool live = true;
+    int ltrips = 0;
+    while (__any(live)) {
         if (live) {
             double f = 0, g[4] = {0, 0, 0, 0};
             if (opt_cache_hit(o)) { f = o.lf; g[0] = o.lg[0]; g[1] = o.lg[1]; g[2] = o.lg[2]; g[3] = o.lg[3]; }
@@ -356,7 +312,8 @@ __global__ __launch_bounds__(64) void klhr_fit2_kernel(const KParams p) {
                 npass++;
             }
             opt_advance<false, N>(o, f, g);
-            const bool capped = ++ltrips > KLHR_MAX_PASSES;
+            ++ltrips;
+            const bool capped = npass > KLHR_MAX_PASSES;
             if (o.pc == PC_DONE || capped) {
 #pragma unroll
                 for (int k = 0; k < 4; k++) p.d_eta[task * 4 + k] = o.xk[k];
@@ -365,19 +322,18 @@ __global__ __launch_bounds__(64) void klhr_fit2_kernel(const KParams p) {
                 if (diag) {
                     double *dd = p.d_diag + task * KLHR_NDIAG;
                     dd[KLHR_D_NFEV2] = o.nfev; dd[KLHR_D_NIT2] = o.k; dd[KLHR_D_STATUS2] = o.status; dd[KLHR_D_FUN2] = o.old_fval;
-                    dd[KLHR_D_FALLBACKS] += o.fallbacks; dd[KLHR_D_PASSES] = KLHR_FB(p, F_PASS, task) + npass;       // (diagnostic launches only)
+                    dd[KLHR_D_FALLBACKS] += o.fallbacks; dd[KLHR_D_PASSES] = npass1 + npass;       // (diagnostic launches only)
                 }
+                ph = PHS_TAIL;
                 live = false;
-                finished = true;
+            } else if (ltrips >= budget) {
+                opt_save(p, task, o, npass);
+                ph = PHS_FIT2_RESUME;
+                live = false;
             }
         }
-        bool exhausted;
-        const long long nt = fq_end(q, want, lane, exhausted);
-        if (want && nt >= 0) { task = nt; fresh = true; want = false; }
-        if (finished) want = true;
-        if (exhausted) want = false;
-        if (!__any(live || fresh || want)) break;
     }
+    if (p.async_mode) p.phase[task] = ph;
 }
 
 // KL / line probes of the C ABI (klhr_kl_eval, klhr_line_eval): one evaluation per chain at eta = d_eta
@@ -601,11 +557,21 @@ __global__ __launch_bounds__(256) void klhr_stream_kernel(const KParams p, const
         for (int i = threadIdx.x; i < 256; i += blockDim.x) { zwi[i] = KLHR_ZIG_WI[i]; zki[i] = KLHR_ZIG_KI[i]; }
         __syncthreads();
     }
-    if (blockIdx.x == 0 && wv == 0) {      // empty the sub-queues of the two fit launches that follow
-        p.qhead[lane * KLHR_QSTRIDE] = 0;
-        p.qhead[(KLHR_NQ + lane) * KLHR_QSTRIDE] = 0;
-    }
     if (lane >= W || c >= p.C) return;
+    // async mode: a chain takes part in this launch with the tail of its finished fit (PHS_TAIL) and / or the head of its
+    // next iteration (PHS_HEAD, while it has draws to go); chains in the middle of a fit sit the launch out
+    int ph = PHS_HEAD;
+    bool run_tail = do_tail != 0, run_head = do_head != 0;
+    if (p.async_mode) {
+        ph = p.phase[c];
+        run_tail = ph == PHS_TAIL;
+        const bool mid_fit = ph != PHS_TAIL && ph != PHS_HEAD;
+        const bool more = p.togo[c] - (run_tail ? 1 : 0) > 0;                         // draws still to go after this launch's tail
+        run_head = !mid_fit && more;
+        const unsigned long long busy = __ballot(mid_fit || run_head);               // chains with work left after this launch
+        if (busy && lane == (int)(__ffsll((long long)busy) - 1)) atomicAdd(p.pend, (unsigned int)__popcll(busy));
+        if (mid_fit || (!run_tail && !run_head)) return;
+    }
     const long long tb = tile * D * W + lane;
     const long long tbe = tile * D * nc * W + lane;
     const long long tbv = tile * D * K * W + lane;
@@ -626,7 +592,7 @@ __global__ __launch_bounds__(256) void klhr_stream_kernel(const KParams p, const
 
     KLHR_STAMP(st_state);
     // =================================================================== tail of iteration k (klhr_sinh.py:266-287)
-    if (do_tail) {
+    if (run_tail) {
         // grad_evals += nfev1 + 8 nfev2 of the fit that preceded this tail (klhr_sinh.py:188,200)
         if (p.phases & PH_FIT) p.grad_evals[c] += (long long)KLHR_FB(p, F_NFEV1, c) + 8 * (long long)KLHR_FB(p, F_NFEV2, c);
         const bool mh = (p.phases & PH_MH) != 0, adapt = (p.phases & PH_ADAPT) != 0;
@@ -671,7 +637,10 @@ __global__ __launch_bounds__(256) void klhr_stream_kernel(const KParams p, const
         const bool upd = adapt && !closed;
         if (upd) omN += 1;
         const double w = 1.0 / (double)omN;
-        double *out = p.draws ? p.draws + ((long long)p.draw_slot * p.C + c) * D : nullptr;
+        // recorded draws: slot = the chain's own draw index within this call (chains may be rounds apart in async mode)
+        long long slot = (long long)p.draw_slot;
+        if (p.async_mode) { const int tg = p.togo[c]; slot = (long long)p.n_iters - tg; p.togo[c] = tg - 1; }
+        double *out = p.draws ? p.draws + slot * p.draw_stride + c * D : nullptr;
         // ---- pass T1: theta' = a (theta + zp rho) + (1 - a) theta; OnlineMoments(theta'); Z = theta' - mean
         double d2 = 0.0, ssq = 0.0;
         bool fin = true;
@@ -761,7 +730,7 @@ __global__ __launch_bounds__(256) void klhr_stream_kernel(const KParams p, const
     }
 
     // =================================================================== head of iteration k+1 (klhr_sinh.py:264-265)
-    if (do_head) {
+    if (run_head) {
         double nn = 1.0;
         LineStat st = {0, 0, 0, 0, 0, 0, 0};
         double Bs = 0, Cs = 0, m1 = 0;       // direction sums, still on the unnormalised r
@@ -868,6 +837,7 @@ __global__ __launch_bounds__(256) void klhr_stream_kernel(const KParams p, const
     }
 
     // ---- store the per-chain scalars
+    if (p.async_mode) p.phase[c] = run_head ? PHS_FIT1 : PHS_HEAD;
     p.rng[c * 4 + 0] = rng.sh; p.rng[c * 4 + 1] = rng.sl; p.rng[c * 4 + 2] = rng.ih; p.rng[c * 4 + 3] = rng.il;
     p.counters[c * 4 + 0] = draw; p.counters[c * 4 + 1] = omN; p.counters[c * 4 + 2] = pcan; p.counters[c * 4 + 3] = cidx;
     p.acc[c] = acc;
