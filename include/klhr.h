@@ -190,6 +190,25 @@ KLHR_API int klhr_pool_gram(klhr_sampler *s, int64_t first_iter, int64_t n_iters
  * row major, ncol = J or J + 1 with eigen_method_one) and eigenvalues (ncol) for every chain.                         */
 KLHR_API int klhr_pool_apply_full(klhr_sampler *s, const double *mean, const double *cov_diag, const double *eigvecs, const double *eigvals);
 
+/* ---- the collective of the pooled mode, inside the library (RCCL over xGMI; librccl.so is loaded on first use) ----------
+ * One process per GPU.  Rank 0 calls klhr_comm_unique_id and hands the bytes to the other ranks by any host channel
+ * (bench.py: the torch.distributed gloo group it already has for its barrier; a file works too); every rank then calls
+ * klhr_comm_init on its handle.  Per adaptation window:  klhr_pool_reset  ->  klhr_pool_accumulate for each recorded
+ * segment (LDS-tiled v_mfma_f64_16x16x4_f64 Gram kernel, X read once, statistics stay on the device)  ->
+ * klhr_pool_allreduce (packs [count, sum theta, sum theta theta^T] and sums it over the ranks with ONE ncclAllReduce of
+ * 1 + D + D^2 doubles on the handle's stream; without a communicator it only packs)  ->  klhr_pool_fetch (one D2H copy)
+ * -> host eigen-decomposition  ->  klhr_pool_apply_full.  No PyTorch anywhere on this path.
+ * replaces: nothing in the reference (its fan-out is `parallel -j` over independent processes, run_experiments:27);
+ * this is the north-star's "RCCL all-reduce ... to pool the online-PCA covariance across shards".                         */
+#define KLHR_COMM_ID_BYTES 128
+KLHR_API int klhr_comm_unique_id(void *id_out, size_t bytes);
+KLHR_API int klhr_comm_init(klhr_sampler *s, const void *id_in, size_t bytes, int rank, int world);
+KLHR_API int klhr_comm_world(const klhr_sampler *s);            /* 0: no communicator */
+KLHR_API int klhr_pool_reset(klhr_sampler *s);
+KLHR_API int klhr_pool_accumulate(klhr_sampler *s, int64_t first_iter, int64_t n_iters);
+KLHR_API int klhr_pool_allreduce(klhr_sampler *s);
+KLHR_API int klhr_pool_fetch(klhr_sampler *s, double *out, size_t n_out);
+
 /* ---- timing ---------------------------------------------------------------------------------- */
 /* HIP-event time (ms) of the kernels launched by the most recent klhr_step on the handle's stream,
  * and the number of kernel launches it made.                                                      */

@@ -80,6 +80,13 @@ def lib():
         "klhr_pool_gram": (C.c_int, [vp, C.c_int64, C.c_int64, dp, C.c_size_t]),
         "klhr_pool_apply_full": (C.c_int, [vp, dp, dp, dp, dp]),
         "klhr_last_step_timing": (C.c_int, [vp, dp, C.POINTER(C.c_int)]),
+        "klhr_comm_unique_id": (C.c_int, [vp, C.c_size_t]),
+        "klhr_comm_init": (C.c_int, [vp, vp, C.c_size_t, C.c_int, C.c_int]),
+        "klhr_comm_world": (C.c_int, [vp]),
+        "klhr_pool_reset": (C.c_int, [vp]),
+        "klhr_pool_accumulate": (C.c_int, [vp, C.c_int64, C.c_int64]),
+        "klhr_pool_allreduce": (C.c_int, [vp]),
+        "klhr_pool_fetch": (C.c_int, [vp, dp, C.c_size_t]),
         "klhr_set_kernel_profiling": (C.c_int, [vp, C.c_int]),
         "klhr_last_kernel_times": (C.c_int, [vp, dp, C.POINTER(C.c_int)]),
     }
@@ -97,11 +104,21 @@ EXPORTS = ["klhr_create", "klhr_destroy", "klhr_last_error", "klhr_abi_version",
            "klhr_fit", "klhr_metropolis", "klhr_adapt", "klhr_set_slice", "klhr_slice_step", "klhr_kl_eval", "klhr_line_eval", "klhr_log_density_gradient",
            "klhr_primitives", "klhr_get_state", "klhr_set_state", "klhr_mh_seed", "klhr_mh_step", "klhr_pool_stats",
            "klhr_pool_apply", "klhr_pool_gram", "klhr_pool_apply_full", "klhr_last_step_timing", "klhr_set_kernel_profiling",
-           "klhr_last_kernel_times"]
+           "klhr_last_kernel_times", "klhr_comm_unique_id", "klhr_comm_init", "klhr_comm_world", "klhr_pool_reset", "klhr_pool_accumulate",
+           "klhr_pool_allreduce", "klhr_pool_fetch"]
 
 
 def device_count():
     return lib().klhr_device_count()
+
+
+def comm_unique_id():
+    """128 bytes identifying a new RCCL communicator (rank 0 creates it, every rank passes it to Sampler.comm_init)."""
+    buf = C.create_string_buffer(128)
+    rc = lib().klhr_comm_unique_id(buf, 128)
+    if rc != 0:
+        raise KlhrError(f"klhr_comm_unique_id failed ({rc}): {lib().klhr_last_error(None).decode()}")
+    return buf.raw
 
 
 def dptr(a):
@@ -115,9 +132,15 @@ def seed_state(seed):
 
 
 def window_closures(warmup, windowsize=25, windowscale=2):
-    buf = (C.c_int64 * 64)()
-    n = lib().klhr_window_closures(int(warmup), int(windowsize), int(windowscale), buf, 64)
-    return [int(buf[i]) for i in range(min(n, 64))]
+    """WindowedAdaptation(warmup, windowsize, windowscale)._closures: the count first, then a buffer of that size
+    (windowscale = 1 gives warmup / windowsize closures: any number)."""
+    L = lib()
+    n = L.klhr_window_closures(int(warmup), int(windowsize), int(windowscale), None, 0)
+    if n <= 0:
+        return []
+    buf = (C.c_int64 * n)()
+    L.klhr_window_closures(int(warmup), int(windowsize), int(windowscale), buf, n)
+    return [int(buf[i]) for i in range(n)]
 
 
 class Sampler:
@@ -326,6 +349,28 @@ class Sampler:
         """[count, sum theta (D), sum theta theta^T (D, D)] over recorded draws [first, first + n) — fp64 MFMA Gram kernel."""
         out = np.empty(1 + self.D + self.D * self.D)
         self._ck(self._L.klhr_pool_gram(self._h, int(first), int(n), dptr(out), out.size), "klhr_pool_gram")
+        return out
+
+    # ---- the collective inside the library (RCCL)
+    def comm_init(self, id_bytes, rank, world):
+        buf = C.create_string_buffer(bytes(id_bytes), 128)
+        self._ck(self._L.klhr_comm_init(self._h, buf, 128, int(rank), int(world)), "klhr_comm_init")
+
+    def comm_world(self):
+        return self._L.klhr_comm_world(self._h)
+
+    def pool_reset(self):
+        self._ck(self._L.klhr_pool_reset(self._h), "klhr_pool_reset")
+
+    def pool_accumulate(self, first, n):
+        self._ck(self._L.klhr_pool_accumulate(self._h, int(first), int(n)), "klhr_pool_accumulate")
+
+    def pool_allreduce(self):
+        self._ck(self._L.klhr_pool_allreduce(self._h), "klhr_pool_allreduce")
+
+    def pool_fetch(self):
+        out = np.empty(1 + self.D + self.D * self.D)
+        self._ck(self._L.klhr_pool_fetch(self._h, dptr(out), out.size), "klhr_pool_fetch")
         return out
 
     def pool_apply_full(self, mean, cov_diag, eigvecs, eigvals):

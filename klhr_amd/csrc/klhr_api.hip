@@ -32,6 +32,37 @@ using namespace klhr;
 
 static thread_local std::string g_create_err;
 
+// RCCL is loaded on first use (dlopen): the library has no link-time dependency on it, single-GPU users never touch it.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+namespace {
+struct RcclApi {
+    void *h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+RcclApi &rccl() {
+    static RcclApi a;
+    if (a.h) return a;
+    for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+        a.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (a.h) break;
+    }
+    if (!a.h) return a;
+    a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(a.h, "ncclGetUniqueId");
+    a.CommInitRank = (decltype(a.CommInitRank))dlsym(a.h, "ncclCommInitRank");
+    a.AllReduce = (decltype(a.AllReduce))dlsym(a.h, "ncclAllReduce");
+    a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.h, "ncclCommDestroy");
+    a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.h, "ncclGetErrorString");
+    a.ok = a.GetUniqueId && a.CommInitRank && a.AllReduce && a.CommDestroy && a.GetErrorString;
+    return a;
+}
+}  // namespace
+
 // HIP streams of a device, shared by every handle on it and kept for the life of the process.  HIP maps streams onto a few
 // hardware queues in creation order; streams created and destroyed per handle ended up, for later handles of a process,
 // with two chain groups on ONE hardware queue — their kernels then ran one after the other (measured: funnel-100 x 131 072
@@ -63,6 +94,10 @@ struct klhr_sampler {
     hipEvent_t gev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr;
     // per-kernel timing of the split pipeline (klhr_set_kernel_profiling): events between the kernels of every iteration
+    // pooled adaptation: device-resident Gram (Dp x Dp) and packed statistics (1 + D + D^2), RCCL communicator
+    double *d_gram = nullptr, *d_pool = nullptr;
+    void *comm = nullptr;
+    int comm_rank = 0, comm_world = 0;
     bool async_ok = false;       // klhr_step lets chains progress asynchronously (split pipeline)
     unsigned int *h_pend = nullptr;      // pinned host copy of the groups' pending-chain counters
     bool profile = false;
@@ -143,18 +178,24 @@ extern "C" void klhr_seed_state(uint64_t seed, uint64_t out4[4]) {
     out4[3] = (uint64_t)inc;
 }
 
-// WindowedAdaptation._calculate_windows (windowedadaptation.py:12-28)
+// WindowedAdaptation._calculate_windows (windowedadaptation.py:12-28): `for w in range(warmup + 1): if w == closewindow:
+// record, then closewindow = next`.  Restated as a walk over the closures themselves; it ends when the next closure does
+// not lie ahead of the loop variable (windowsize == 0, windowscale <= 0: the reference records one closure and never
+// meets another) or lies beyond warmup.  Intermediate products in 128 bits: no overflow for any int64 arguments.
 extern "C" int klhr_window_closures(int64_t warmup, int64_t windowsize, int64_t windowscale, int64_t *out, int cap) {
+    typedef __int128 i128;
     int n = 0;
     if (!(warmup > windowsize)) return 0;
-    int64_t ws = windowsize, close = windowsize;
-    while (close <= warmup) {
-        if (n < cap && out) out[n] = close;
+    i128 ws = windowsize, close = windowsize;
+    while (close >= 0 && close <= warmup) {
+        if (n < cap && out) out[n] = (int64_t)close;
         n++;
-        if (close == warmup) break;
+        if (n >= (1 << 24)) break;                      // (a schedule this long is refused by klhr_create)
         ws *= windowscale;
-        int64_t next = close + ws;
-        close = (close + windowscale * ws >= warmup) ? warmup : next;
+        if (ws > (i128)1 << 100 || ws < -((i128)1 << 100)) ws = ws > 0 ? (i128)1 << 100 : -((i128)1 << 100);
+        const i128 next = (close + (i128)windowscale * ws >= warmup) ? (i128)warmup : close + ws;
+        if (next <= close) break;                       // the loop variable has passed it: no further closure
+        close = next;
     }
     return n;
 }
@@ -417,6 +458,9 @@ extern "C" void klhr_destroy(klhr_sampler *s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (hipEvent_t e : s->pev) (void)hipEventDestroy(e);
     if (s->h_pend) (void)hipHostFree(s->h_pend);
+    if (s->comm && rccl().ok) (void)rccl().CommDestroy((ncclComm_t)s->comm);
+    if (s->d_gram) (void)hipFree(s->d_gram);
+    if (s->d_pool) (void)hipFree(s->d_pool);
     for (void *p : s->allocs) (void)hipFree(p);
     if (s->d_draws) (void)hipFree(s->d_draws);
     for (int g = 1; g < 4; g++) {
@@ -1049,42 +1093,143 @@ extern "C" int klhr_pool_apply(klhr_sampler *s, const double *mean, const double
     return rc;
 }
 
-extern "C" int klhr_pool_gram(klhr_sampler *s, int64_t first_iter, int64_t n_iters, double *out, size_t n_out) {
-    if (!s || !out || first_iter < 0 || n_iters < 1 || first_iter + n_iters > s->draws_iters) return KLHR_ERR_ARG;
-    const int D = s->D;
-    if (n_out != (size_t)(1 + D + (size_t)D * D)) return KLHR_ERR_ARG;
+// ---- pooled full covariance: device-resident statistics, LDS-tiled MFMA Gram, RCCL all-reduce inside the library ------
+
+extern "C" int klhr_comm_unique_id(void *id_out, size_t bytes) {
+    if (!id_out || bytes < sizeof(ncclUniqueId)) return KLHR_ERR_ARG;
+    RcclApi &r = rccl();
+    if (!r.ok) { g_create_err = "klhr_comm_unique_id: librccl.so could not be loaded"; return KLHR_ERR_HIP; }
+    ncclUniqueId id;
+    if (r.GetUniqueId(&id) != ncclSuccess) { g_create_err = "ncclGetUniqueId failed"; return KLHR_ERR_HIP; }
+    memset(id_out, 0, bytes);
+    memcpy(id_out, &id, sizeof id);
+    return KLHR_OK;
+}
+
+extern "C" int klhr_comm_init(klhr_sampler *s, const void *id_in, size_t bytes, int rank, int world) {
+    if (!s || !id_in || bytes < sizeof(ncclUniqueId) || world < 1 || rank < 0 || rank >= world) return KLHR_ERR_ARG;
+    RcclApi &r = rccl();
+    if (!r.ok) { s->err = "klhr_comm_init: librccl.so could not be loaded"; return KLHR_ERR_HIP; }
     HIPCHECK(s, hipSetDevice(s->cfg.device));
-    const int Dp = ((D + 1 + 15) / 16) * 16;
+    if (s->comm) { (void)r.CommDestroy((ncclComm_t)s->comm); s->comm = nullptr; }
+    ncclUniqueId id;
+    memcpy(&id, id_in, sizeof id);
+    ncclComm_t c = nullptr;
+    const ncclResult_t rc = r.CommInitRank(&c, world, id, rank);
+    if (rc != ncclSuccess) { s->err = std::string("ncclCommInitRank failed: ") + r.GetErrorString(rc); return KLHR_ERR_HIP; }
+    s->comm = c; s->comm_rank = rank; s->comm_world = world;
+    return KLHR_OK;
+}
+extern "C" int klhr_comm_world(const klhr_sampler *s) { return s ? s->comm_world : KLHR_ERR_ARG; }
+
+static int pool_buffers(klhr_sampler *s) {
+    if (s->d_pool) return 0;
+    const int D = s->D, Dp = ((D + 1 + 15) / 16) * 16;
+    HIPCHECK(s, hipMalloc((void **)&s->d_gram, (size_t)Dp * Dp * 8));
+    HIPCHECK(s, hipMalloc((void **)&s->d_pool, ((size_t)1 + D + (size_t)D * D) * 8));
+    HIPCHECK(s, hipMemsetAsync(s->d_gram, 0, (size_t)Dp * Dp * 8, s->stream));
+    HIPCHECK(s, hipMemsetAsync(s->d_pool, 0, ((size_t)1 + D + (size_t)D * D) * 8, s->stream));
+    return 0;
+}
+
+extern "C" int klhr_pool_reset(klhr_sampler *s) {
+    if (!s) return KLHR_ERR_ARG;
+    HIPCHECK(s, hipSetDevice(s->cfg.device));
+    int rc = pool_buffers(s);
+    if (rc) return rc;
+    const int D = s->D, Dp = ((D + 1 + 15) / 16) * 16;
+    HIPCHECK(s, hipMemsetAsync(s->d_gram, 0, (size_t)Dp * Dp * 8, s->stream));
+    return KLHR_OK;
+}
+
+template <int T>
+static void launch_gram(klhr_sampler *s, const double *X, long long nrows, long long rps, unsigned slabs, double *G) {
+    constexpr int DpS = T * 16 + ((T % 2 == 0) ? 16 : 0);
+    const size_t lds = (size_t)GRAM_ROWS * DpS * sizeof(double);
+    hipLaunchKernelGGL(klhr_gram_lds_kernel<T>, dim3(slabs), dim3(256), lds, s->stream, X, nrows, s->D, rps, s->kp.status, s->C, G);
+}
+
+// += Gram statistics of the recorded draws [first_iter, first_iter + n_iters) into the handle's device-resident buffer;
+// asynchronous on the handle's stream, no allocation, no host copy
+extern "C" int klhr_pool_accumulate(klhr_sampler *s, int64_t first_iter, int64_t n_iters) {
+    if (!s || first_iter < 0 || n_iters < 1 || first_iter + n_iters > s->draws_iters) return KLHR_ERR_ARG;
+    HIPCHECK(s, hipSetDevice(s->cfg.device));
+    int rc = pool_buffers(s);
+    if (rc) return rc;
+    const int D = s->D, Dp = ((D + 1 + 15) / 16) * 16, T = Dp / 16;
     const long long nrows = (long long)n_iters * s->C;
-    double *d_G = nullptr;
-    HIPCHECK(s, hipMalloc((void **)&d_G, (size_t)Dp * Dp * 8));
-    int rc = 0;
-    {
-        hipError_t e = hipMemsetAsync(d_G, 0, (size_t)Dp * Dp * 8, s->stream);
-        if (e != hipSuccess) { s->err = hipGetErrorString(e); rc = KLHR_ERR_HIP; }
-    }
-    if (!rc) {
+    const double *X = s->d_draws + (size_t)first_iter * s->C * D;
+    if (T <= 8) {
+        // LDS-tiled kernel: X read once.  Slabs: ~4 workgroups per CU, whole chunks of GRAM_ROWS rows
+        long long slabs = 1024;
+        long long rps = (nrows + slabs - 1) / slabs;
+        rps = (rps + GRAM_ROWS - 1) / GRAM_ROWS * GRAM_ROWS;
+        slabs = (nrows + rps - 1) / rps;
+        switch (T) {
+        case 1: launch_gram<1>(s, X, nrows, rps, (unsigned)slabs, s->d_gram); break;
+        case 2: launch_gram<2>(s, X, nrows, rps, (unsigned)slabs, s->d_gram); break;
+        case 3: launch_gram<3>(s, X, nrows, rps, (unsigned)slabs, s->d_gram); break;
+        case 4: launch_gram<4>(s, X, nrows, rps, (unsigned)slabs, s->d_gram); break;
+        case 5: launch_gram<5>(s, X, nrows, rps, (unsigned)slabs, s->d_gram); break;
+        case 6: launch_gram<6>(s, X, nrows, rps, (unsigned)slabs, s->d_gram); break;
+        case 7: launch_gram<7>(s, X, nrows, rps, (unsigned)slabs, s->d_gram); break;
+        default: launch_gram<8>(s, X, nrows, rps, (unsigned)slabs, s->d_gram); break;
+        }
+    } else {
+        // D > 127: one wavefront per tile pair and slab (re-reads X once per tile column)
         const int tiles = Dp / 16;
         long long slabs = (nrows + 8191) / 8192;
         if (slabs > 4096) slabs = 4096;
         long long rps = (nrows + slabs - 1) / slabs;
         rps = (rps + 3) / 4 * 4;
         slabs = (nrows + rps - 1) / rps;
-        const double *X = s->d_draws + (size_t)first_iter * s->C * D;
-        hipLaunchKernelGGL(klhr_gram_mfma_kernel, dim3(tiles * tiles, (unsigned)slabs), dim3(64), 0, s->stream, X, nrows, D, Dp, rps, s->kp.status, s->C, d_G);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) { s->err = hipGetErrorString(e); rc = KLHR_ERR_HIP; }
+        hipLaunchKernelGGL(klhr_gram_mfma_kernel, dim3(tiles * tiles, (unsigned)slabs), dim3(64), 0, s->stream, X, nrows, D, Dp, rps, s->kp.status, s->C, s->d_gram);
     }
-    std::vector<double> G((size_t)Dp * Dp);
-    if (!rc) rc = d2h(s, G.data(), d_G, G.size() * 8);
-    (void)hipFree(d_G);
-    if (rc) return rc;
-    auto g = [&](int i, int j) { return i <= j ? G[(size_t)i * Dp + j] : G[(size_t)j * Dp + i]; };   // upper-triangle tiles
-    out[0] = g(D, D);
-    for (int i = 0; i < D; i++) out[1 + i] = g(i, D);
-    for (int i = 0; i < D; i++)
-        for (int j = 0; j < D; j++) out[1 + D + (size_t)i * D + j] = 0.5 * (g(i, j) + g(j, i));
+    HIPCHECK(s, hipGetLastError());
     return KLHR_OK;
+}
+
+// pack the accumulated Gram into [count, sum theta (D), sum theta theta^T (D x D)] and sum it over the ranks of the
+// communicator: one ncclAllReduce of 1 + D + D^2 doubles on the handle's stream, in place on the device (RCCL over xGMI).
+// Without a communicator (single GPU) only the packing runs.
+extern "C" int klhr_pool_allreduce(klhr_sampler *s) {
+    if (!s) return KLHR_ERR_ARG;
+    HIPCHECK(s, hipSetDevice(s->cfg.device));
+    int rc = pool_buffers(s);
+    if (rc) return rc;
+    const int D = s->D, Dp = ((D + 1 + 15) / 16) * 16, n = 1 + D + D * D;
+    hipLaunchKernelGGL(klhr_gram_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->d_gram, D, Dp, s->d_pool);
+    HIPCHECK(s, hipGetLastError());
+    if (s->comm && s->comm_world > 1) {
+        RcclApi &r = rccl();
+        const ncclResult_t nrc = r.AllReduce(s->d_pool, s->d_pool, (size_t)n, ncclDouble, ncclSum, (ncclComm_t)s->comm, s->stream);
+        if (nrc != ncclSuccess) { s->err = std::string("ncclAllReduce failed: ") + r.GetErrorString(nrc); return KLHR_ERR_HIP; }
+    } else if (s->comm) {
+        // a one-rank communicator: still goes through RCCL (the path the multi-GPU job takes; used by the 1-GPU test)
+        RcclApi &r = rccl();
+        const ncclResult_t nrc = r.AllReduce(s->d_pool, s->d_pool, (size_t)n, ncclDouble, ncclSum, (ncclComm_t)s->comm, s->stream);
+        if (nrc != ncclSuccess) { s->err = std::string("ncclAllReduce failed: ") + r.GetErrorString(nrc); return KLHR_ERR_HIP; }
+    }
+    return KLHR_OK;
+}
+
+extern "C" int klhr_pool_fetch(klhr_sampler *s, double *out, size_t n_out) {
+    if (!s || !out || n_out != (size_t)(1 + s->D + (size_t)s->D * s->D)) return KLHR_ERR_ARG;
+    if (!s->d_pool) { s->err = "klhr_pool_fetch: nothing accumulated"; return KLHR_ERR_STATE; }
+    return d2h(s, out, s->d_pool, n_out * 8);
+}
+
+// one-call form (kept from ABI version 1): statistics of a range of recorded draws, this GPU only
+extern "C" int klhr_pool_gram(klhr_sampler *s, int64_t first_iter, int64_t n_iters, double *out, size_t n_out) {
+    if (!s || !out || first_iter < 0 || n_iters < 1 || first_iter + n_iters > s->draws_iters) return KLHR_ERR_ARG;
+    if (n_out != (size_t)(1 + s->D + (size_t)s->D * s->D)) return KLHR_ERR_ARG;
+    int rc = klhr_pool_reset(s);
+    if (!rc) rc = klhr_pool_accumulate(s, first_iter, n_iters);
+    if (rc) return rc;
+    const int D = s->D, Dp = ((D + 1 + 15) / 16) * 16, n = 1 + D + D * D;
+    hipLaunchKernelGGL(klhr_gram_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->d_gram, D, Dp, s->d_pool);
+    HIPCHECK(s, hipGetLastError());
+    return klhr_pool_fetch(s, out, n_out);
 }
 
 extern "C" int klhr_pool_apply_full(klhr_sampler *s, const double *mean, const double *cov_diag, const double *eigvecs, const double *eigvals) {

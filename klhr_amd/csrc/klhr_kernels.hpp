@@ -1130,6 +1130,95 @@ __global__ __launch_bounds__(64) void klhr_gram_mfma_kernel(const double *X, lon
     }
 }
 
+// LDS-tiled form: X is read from HBM exactly once.  A workgroup of 4 wavefronts owns a slab of rows; chunks of GR rows x Dp
+// columns (ones column at D, zero padding beyond) are staged in LDS by coalesced copies, every wavefront accumulates its
+// share of the T(T+1)/2 upper-triangular 16x16 tiles (pair p goes to wavefront p % 4) with one v_mfma_f64_16x16x4_f64 per
+// tile and 4 rows: per step a wavefront reads its T column fragments from LDS once and issues one MFMA per pair.
+// Slab partials are combined with fp64 atomic adds into G (Dp x Dp, upper-triangle tiles; zeroed by the caller).
+constexpr int GRAM_ROWS = 32;
+template <int T, int WID>
+__device__ __forceinline__ void gram_wave(const double *Xs, int DpS, int lane, int nrows_chunk, klhr_d4 (&acc)[(T * (T + 1) / 2 + 3) / 4]) {
+    const int cl = lane & 15, kk = lane >> 4;
+    for (int k0 = 0; k0 < nrows_chunk; k0 += 4) {
+        double frag[T];
+#pragma unroll
+        for (int t = 0; t < T; t++) frag[t] = Xs[(k0 + kk) * DpS + t * 16 + cl];
+        int p = 0, slot = 0;
+#pragma unroll
+        for (int ti = 0; ti < T; ti++)
+#pragma unroll
+            for (int tj = ti; tj < T; tj++) {
+                if (p % 4 == WID) { acc[slot] = __builtin_amdgcn_mfma_f64_16x16x4f64(frag[ti], frag[tj], acc[slot], 0, 0, 0); slot++; }
+                p++;
+            }
+    }
+}
+template <int T, int WID>
+__device__ __forceinline__ void gram_flush(double *G, int Dp, int lane, const klhr_d4 (&acc)[(T * (T + 1) / 2 + 3) / 4]) {
+    int p = 0, slot = 0;
+#pragma unroll
+    for (int ti = 0; ti < T; ti++)
+#pragma unroll
+        for (int tj = ti; tj < T; tj++) {
+            if (p % 4 == WID) {
+                const int j = tj * 16 + (lane & 15);
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) atomicAdd(&G[(long long)(ti * 16 + 4 * rr + (lane >> 4)) * Dp + j], acc[slot][rr]);
+                slot++;
+            }
+            p++;
+        }
+}
+template <int T>
+__global__ __launch_bounds__(256) void klhr_gram_lds_kernel(const double *X, long long nrows, int D, long long rows_per_slab, const int *status, int C, double *G) {
+    extern __shared__ double Xs[];            // [GRAM_ROWS][DpS]
+    constexpr int Dp = T * 16;
+    // LDS row stride: consecutive rows of a ds_read_b64's 32-lane group must sit 32 banks apart (stride = 32 dwords mod 64)
+    constexpr int DpS = Dp + ((T % 2 == 0) ? 16 : 0);
+    constexpr int NACC = (T * (T + 1) / 2 + 3) / 4;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const long long r_begin = (long long)blockIdx.x * rows_per_slab;
+    long long r_end = r_begin + rows_per_slab;
+    if (r_end > nrows) r_end = nrows;
+    klhr_d4 acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; i++) acc[i] = klhr_d4{0.0, 0.0, 0.0, 0.0};
+    for (long long r0 = r_begin; r0 < r_end; r0 += GRAM_ROWS) {
+        const int nr = (int)((r_end - r0) < GRAM_ROWS ? (r_end - r0) : GRAM_ROWS);
+        __syncthreads();
+        // stage: rows r0 .. r0+nr-1 (contiguous nr*D doubles in X), ones column, zero padding; rows of non-finite chains zeroed
+        for (int idx = tid; idx < GRAM_ROWS * Dp; idx += 256) {
+            const int r = idx / Dp, col = idx - r * Dp;
+            double v = 0.0;
+            if (r < nr && !(status[(r0 + r) % C] & 2)) v = col < D ? X[(r0 + r) * (long long)D + col] : (col == D ? 1.0 : 0.0);
+            Xs[r * DpS + col] = v;
+        }
+        __syncthreads();
+        const int nr4 = (nr + 3) & ~3;        // (rows beyond nr are zero)
+        if (wid == 0) gram_wave<T, 0>(Xs, DpS, lane, nr4, acc);
+        else if (wid == 1) gram_wave<T, 1>(Xs, DpS, lane, nr4, acc);
+        else if (wid == 2) gram_wave<T, 2>(Xs, DpS, lane, nr4, acc);
+        else gram_wave<T, 3>(Xs, DpS, lane, nr4, acc);
+    }
+    if (wid == 0) gram_flush<T, 0>(G, Dp, lane, acc);
+    else if (wid == 1) gram_flush<T, 1>(G, Dp, lane, acc);
+    else if (wid == 2) gram_flush<T, 2>(G, Dp, lane, acc);
+    else gram_flush<T, 3>(G, Dp, lane, acc);
+}
+
+// G (Dp x Dp, upper-triangle tiles) -> packed statistics += [count, sum theta (D), sum theta theta^T (D x D, symmetric)]
+__global__ void klhr_gram_pack_kernel(const double *G, int D, int Dp, double *pool) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = 1 + D + D * D;
+    if (idx >= n) return;
+    auto g = [&](int i, int j) { return i <= j ? G[(long long)i * Dp + j] : G[(long long)j * Dp + i]; };
+    double v;
+    if (idx == 0) v = g(D, D);
+    else if (idx <= D) v = g(idx - 1, D);
+    else { const int k = idx - 1 - D, i = k / D, j = k - i * D; v = g(i, j); }
+    pool[idx] = v;
+}
+
 __global__ void klhr_pool_apply_full_kernel(const KParams p, const double *mean_in, const double *cov_in, const double *evec_in, const double *eval_in) {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= p.C) return;

@@ -4,8 +4,11 @@ Parity mode (default) has NO data-path collective: every chain owns its RNG and 
 one reference process per chain would (run_experiments:27 fans out with GNU parallel).  The optional pooled-adaptation
 mode (an extension; NOT reference behaviour) all-reduces, at window closures only, the sufficient
 statistics [n, sum theta, sum theta^2] (1 + 2D doubles: latency-bound over xGMI) and overwrites every chain's
-direction mean / diagonal covariance with the pooled values.  The collective goes through torch.distributed:
-backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
+direction mean / diagonal covariance with the pooled values.  pooled="full" (the north-star's "pool the covariance across shards") keeps everything on the device and inside the library:
+LDS-tiled MFMA Gram of the window's draws -> ONE ncclAllReduce (RCCL over xGMI) of 1 + D + D^2 doubles on the handle's
+stream (klhr_comm_init / klhr_pool_allreduce, include/klhr.h) -> one D2H copy -> eigen-decomposition on every rank.  No
+PyTorch on that path; torch.distributed (gloo) is only the host channel that hands the communicator id to the ranks, and
+the stand-in collective of the CPU tests.
 """
 import os
 
@@ -74,15 +77,94 @@ def pooled_full(stats, D, ncol):
     return mean, np.maximum(np.diag(S), 0.0), np.ascontiguousarray(vecs), vals
 
 
+def exchange_comm_id(rank, world, dist=None):
+    """The 128-byte RCCL communicator id of rank 0 on every rank.  Host plumbing only: torch.distributed (gloo) when a process
+    group is given, else a file named by KLHR_COMM_FILE (rank 0 writes it, the others wait for it)."""
+    from . import _lib
+    if world == 1:
+        return _lib.comm_unique_id()
+    if dist is not None and dist.is_initialized():
+        box = [_lib.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+    path = os.environ.get("KLHR_COMM_FILE")
+    if not path:
+        raise RuntimeError("exchange_comm_id: need a torch.distributed process group or KLHR_COMM_FILE")
+    if rank == 0:
+        with open(path + ".tmp", "wb") as f:
+            f.write(_lib.comm_unique_id())
+        os.replace(path + ".tmp", path)
+    import time
+    for _ in range(6000):
+        if os.path.exists(path):
+            return open(path, "rb").read()
+        time.sleep(0.01)
+    raise RuntimeError("exchange_comm_id: timed out waiting for " + path)
+
+
+def pooled_setup_draws(s, n, rank, world, dist, mode="full", warmup=100, windowsize=50, windowscale=2, segment=50):
+    """bench.py --pooled: run `n` draws on the raw sampler `s` with pooled adaptation at the window closures, the collective
+    inside the library (RCCL).  Returns what was done, with the mean time of an all-reduce call measured on the host."""
+    import time
+    from . import _lib
+    closures = _lib.window_closures(warmup, windowsize, windowscale)
+    D, ncol = s.D, s.ncol
+    # RCCL wants one device per rank: a rehearsal with more ranks than GPUs (ranks sharing a device) sums on the host instead
+    use_rccl = world <= max(1, _lib.device_count())
+    if use_rccl:
+        s.comm_init(exchange_comm_id(rank, world, dist), rank, world)
+    done, times = 0, []
+    s.pool_reset()
+    while done < n:
+        nxt = next((c for c in closures if c > done), None)
+        if nxt is None or nxt - 1 - done >= n - done:
+            k = min(n - done, segment)
+            s.step(k, record_draws=True)
+            done += k
+            continue
+        before = nxt - 1 - done
+        if before > 0:
+            k = min(before, segment)
+            s.step(k, record_draws=True)
+            s.pool_accumulate(0, k)
+            done += k
+            continue
+        s.sync()
+        t0 = time.perf_counter()
+        s.pool_allreduce()
+        tot = s.pool_fetch()
+        if not use_rccl:
+            tot = allreduce_sum(tot, dist)
+        times.append(time.perf_counter() - t0)
+        s.step(1)                                  # the closure iteration (klhr_sinh.py:268-280)
+        done += 1
+        s.pool_reset()
+        if tot[0] > 2 and np.isfinite(tot).all():
+            if mode == "full":
+                s.pool_apply_full(*pooled_full(tot, D, ncol))
+            else:
+                mean = tot[1:1 + D] / tot[0]
+                var = (np.diag(tot[1 + D:].reshape(D, D)) / tot[0] - mean * mean) * tot[0] / max(tot[0] - 1.0, 1.0)
+                s.pool_apply(mean, np.maximum(var, 0.0))
+    return {"mode": mode, "ranks": world,
+            "collective": "ncclAllReduce (RCCL) on the handle's stream, inside libklhr_hip.so" if use_rccl else
+                          "host sum over gloo (rehearsal: ranks share a GPU, RCCL needs one device per rank)",
+            "doubles_per_allreduce": 1 + D + D * D, "closures_pooled": len(times),
+            "allreduce_plus_fetch_ms": [t * 1e3 for t in times]}
+
+
 class ShardedKLHRSINH:
     """All chains of a multi-GPU job behind one object; every rank constructs it with the same arguments."""
 
     SEGMENT = 50        # pooled="full": draws of at most this many iterations are kept on the device at a time
 
-    def __init__(self, bsmodel, chains_total, seed=0, pooled=False, dist=None, **kw):
+    def __init__(self, bsmodel, chains_total, seed=0, pooled=False, dist=None, rccl=None, **kw):
         """pooled: False (parity mode, no collective) | True / "diag" (pool mean + per-coordinate variance) |
         "full" (pool the full covariance: fp64 MFMA Gram of the window's draws per GPU, one all-reduce of
-        1 + D + D^2 doubles per window closure, eigen-decomposition on every rank)."""
+        1 + D + D^2 doubles per window closure, eigen-decomposition on every rank).
+        rccl: pooled="full" only — True: the all-reduce is ncclAllReduce inside the library (default when the process group
+        is not gloo-on-CPU-tensors only, i.e. on a multi-GPU node); False: the statistics are fetched and summed through
+        `dist` (gloo) on the host — the stand-in used by the CPU tests and by rehearsals where ranks share one GPU."""
         from .klhr_sinh import KLHRSINH
         self.rank, self.world, self.local_rank = dist_env()
         from . import _lib
@@ -96,7 +178,11 @@ class ShardedKLHRSINH:
         self._closures = list(self.local._windowedadaptation._closures)
         self._done = 0
         self._full = pooled == "full"
-        self._gram = None
+        self._rccl = bool(rccl) and self._full
+        if self._rccl:
+            self.local._sampler.comm_init(exchange_comm_id(self.rank, self.world, dist), self.rank, self.world)
+        if self._full:
+            self.local._sampler.pool_reset()
 
     def advance(self, n, record=False):
         """n iterations on this rank's shard.  Pooled mode stops in front of each window closure, all-reduces the
@@ -110,9 +196,8 @@ class ShardedKLHRSINH:
                 s.step(kk, record_draws=record or self._full)
                 if record:
                     out.append(s.draws(0, kk))
-                if self._full and accumulate:          # statistics of the open window (the closure draw is excluded)
-                    g = s.pool_gram(0, kk)
-                    self._gram = g if self._gram is None else self._gram + g
+                if self._full and accumulate:          # statistics of the open window (the closure draw is excluded):
+                    s.pool_accumulate(0, kk)           # device-resident, no copy
                 self._done += kk
                 k -= kk
 
@@ -130,11 +215,13 @@ class ShardedKLHRSINH:
                 continue
             if self._full:
                 D = self.local.D
-                mine = self._gram if self._gram is not None else np.zeros(1 + D + D * D)
-                tot = allreduce_sum(mine, self.dist, self.local_rank)
+                s.pool_allreduce()                    # packs; with a communicator: ONE ncclAllReduce on the device
+                tot = s.pool_fetch()
+                if not self._rccl:
+                    tot = allreduce_sum(tot, self.dist, self.local_rank)       # host stand-in (gloo)
                 run(1, accumulate=False)              # the closure iteration (klhr_sinh.py:268-280)
                 left -= 1
-                self._gram = None
+                s.pool_reset()
                 if tot[0] > 2 and np.isfinite(tot).all():
                     s.pool_apply_full(*pooled_full(tot, D, s.ncol))
             else:

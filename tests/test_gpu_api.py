@@ -202,7 +202,9 @@ def test_pooled_full_covariance_single_rank():
     dr = sh.advance(49, record=True)
     s = sh.local._sampler
     X = dr.reshape(-1, 10)
-    assert np.allclose(sh._gram[1 + 10:].reshape(10, 10), X.T @ X, rtol=1e-11, atol=1e-9)
+    s.pool_allreduce()                 # (no communicator: packs the device-resident statistics)
+    acc = s.pool_fetch()
+    assert acc[0] == X.shape[0] and np.allclose(acc[1 + 10:].reshape(10, 10), X.T @ X, rtol=1e-11, atol=1e-9)
     sh.advance(2)                      # crosses the closure at draw 50 -> pooled mean / cov / eigvecs on every chain
     mean, cov, evec, evals = s.get("mean"), s.get("cov"), s.get("eigvecs"), s.get("eigvals")
     assert np.all(mean == mean[0]) and np.all(evec == evec[0]) and np.all(evals == evals[0])
@@ -214,6 +216,47 @@ def test_pooled_full_covariance_single_rank():
     assert abs(abs(evec[0][:, 0] @ V[:, -1]) - 1) < 1e-8
     sh.advance(60)                     # keeps sampling through the second closure with pooled directions
     assert np.isfinite(s.get("theta")).all()
+
+
+def test_pooled_full_through_rccl_single_rank_equals_host_path():
+    """The collective inside the library: klhr_comm_init with a one-rank communicator, klhr_pool_allreduce = ncclAllReduce on
+    the handle's stream.  The pooled values installed on the chains must equal those of the host (no-communicator) path."""
+    from klhr_amd.parallel import ShardedKLHRSINH
+    res = []
+    for use_rccl in (False, True):
+        sh = ShardedKLHRSINH(funnel_model(), 192, seed=11, pooled="full", rccl=use_rccl, warmup=100)
+        s = sh.local._sampler
+        assert s.comm_world() == (1 if use_rccl else 0)
+        sh.advance(50)                 # 49 accumulated draws, all-reduce, closure iteration, pooled values applied
+        res.append((s.get("mean"), s.get("cov"), s.get("eigvecs"), s.get("eigvals"), s.get("theta")))
+        sh.advance(55)                 # through the second closure
+        assert np.isfinite(s.get("theta")).all()
+    # (the Gram kernel combines its slabs with floating-point atomics: two runs agree to rounding, not bit for bit)
+    for a, b in zip(res[0][:4], res[1][:4]):
+        assert np.allclose(a, b, rtol=1e-9, atol=1e-12)
+    assert np.array_equal(res[0][4], res[1][4])        # theta after the closure draw does not depend on the pooled values yet
+
+
+def test_lds_tiled_gram_matches_numpy_over_dimensions():
+    """klhr_pool_accumulate (LDS-tiled MFMA Gram, X read once) for every tile count T = 1..8 and the wide fallback, with row
+    counts that are not multiples of the chunk, accumulated over two segments."""
+    from klhr_amd import _lib
+    for D, C in ((3, 50), (20, 33), (40, 70), (50, 64), (70, 17), (90, 40), (100, 129), (120, 9), (140, 12)):
+        s = _lib.Sampler(_lib.MODEL_IDS["normal"], np.array([float(D)]), C, warmup=100)
+        s.seed(np.arange(C, dtype=np.uint64) + 77)
+        s.step(5, record_draws=True)
+        X1 = s.draws(0, 5).reshape(-1, D)
+        s.pool_reset()
+        s.pool_accumulate(0, 5)
+        s.step(3, record_draws=True)
+        X2 = s.draws(1, 2).reshape(-1, D)
+        s.pool_accumulate(1, 2)
+        s.pool_allreduce()
+        g = s.pool_fetch()
+        X = np.concatenate([X1, X2])
+        assert g[0] == X.shape[0], (D, C)
+        assert np.allclose(g[1:1 + D], X.sum(axis=0), rtol=1e-12, atol=1e-11), (D, C)
+        assert np.allclose(g[1 + D:].reshape(D, D), X.T @ X, rtol=1e-12, atol=1e-10), (D, C)
 
 
 def test_klhr_class_is_the_reference_chain():

@@ -163,3 +163,21 @@ def test_roofline_byte_model():
     assert bench.algorithmic_bytes_per_iter(10) == 1328
     assert bench.algorithmic_bytes_per_iter(45) == 5528
     assert bench.algorithmic_bytes_per_iter(100) == 12128
+
+
+def test_window_closures_degenerate_schedules(lib):
+    """klhr_window_closures on the inputs where a naive restatement of WindowedAdaptation._calculate_windows
+    (windowedadaptation.py:12-28) does not terminate or overflows: windowsize == 0, windowscale <= 0, windowscale == 1 with
+    many windows.  Expected values: the reference class itself, run in the build container (first 12 closures, count, last)."""
+    expected = {(100, 0, 2): ([0], 1, 0), (100, 50, 0): ([50], 1, 50), (100, 50, -1): ([50, 100], 2, 100), (100, 50, 1): ([50, 100], 2, 100),
+                (1000, 50, 1): ([50, 100, 150, 200, 250, 300, 350, 400, 450, 500, 550, 600], 20, 1000), (100, -5, 2): ([], 0, None),
+                (10, 3, 3): ([3, 10], 2, 10), (200, 7, 1): ([7, 14, 21, 28, 35, 42, 49, 56, 63, 70, 77, 84], 29, 200), (0, 50, 2): ([], 0, None),
+                (50, 50, 2): ([], 0, None), (51, 50, 2): ([50, 51], 2, 51),
+                (5000000, 50, 2): ([50, 150, 350, 750, 1550, 3150, 6350, 12750, 25550, 51150, 102350, 204750], 17, 5000000),
+                (100, 1, 1): (list(range(1, 13)), 100, 100)}
+    for (wu, ws, sc), (first, n, last) in expected.items():
+        got = lib.window_closures(wu, ws, sc)
+        assert len(got) == n and got[:12] == first and (n == 0 or got[-1] == last), (wu, ws, sc, got[:14], len(got))
+    # extreme arguments terminate too (128-bit intermediates): no hang, no overflow
+    assert lib.window_closures(2**62, 1, 2**31) == [1, 2**62]        # 1 + 2^31 * 2^31 >= warmup: the second window runs to warmup
+    assert len(lib.window_closures(2**62, 2**40, 3)) < 64
