@@ -36,6 +36,8 @@ def _lint(objdir):
                            "cannot run (did -save-temps change its file naming?)")
     for asm in files:
         out += exec_lint.lint(asm)
+    if os.environ.get("KLHR_BUILD_VERBOSE"):
+        sys.stderr.write(f"klhr_amd.build: {os.path.basename(objdir)}: linted {len(files)} device assembly file(s), {len(out)} block(s) flagged\n")
     return out
 
 

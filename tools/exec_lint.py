@@ -9,8 +9,18 @@ The copies then save nothing and the later reads return stale register contents:
 as garbage (memory fault on p.closures[cidx]) or the MH proposal became a polynomial constant.  The source is correct;
 the placement is a code-generation fault that comes and goes with unrelated edits.
 
-The check: in every block entered through `s_cbranch_execz <label>` or by falling out of `s_cbranch_execnz`, the first
-instruction that writes EXEC must not be preceded by a vector / memory instruction if it is an `s_or_b64 exec, exec, ..`.
+The check: in every block entered through `s_cbranch_execz <label>` (EXEC = 0 when the branch is taken, the surviving
+subset of the lanes when the block is reached by falling through) or by falling out of `s_cbranch_execnz`, walk the
+fall-through path — across `; %bb.N` markers, up to the first branch or label — to the first instruction that writes EXEC.
+If that instruction can ADD lanes (any restore form: `s_or_b64 exec, exec, ..`, `s_mov_b64 exec, ..`, `s_xor_b64 exec, ..`,
+`s_or_saveexec_b64 ..`, ...) no vector / memory / AGPR instruction may precede it: such an instruction ran for a subset of the
+lanes it was meant for.  Lane moves of SGPR spills (`v_writelane` / `v_readlane`) ignore EXEC and are allowed — but they are
+what moves the allocator's insertion point ahead of the restore (tools/ubench/execz_copy.hip reproduces that in 40 lines).
+
+History of the rule ("Code-generation hazard"): round 1 checked only `s_or_b64 exec, exec` directly after the
+label; the two historical builds that can be rebuilt were re-checked in round 2 — the faulting `<glmm-poisson, SUBKLHRSINH,
+over-relaxed>` unit of commit e4cb1ae is flagged (36 AGPR copies ahead of the restore in klhr_iter_kernel<2,true,2>), the
+`-DKLHR_STAMPS` octet build of commit e2cbbed is NOT, by either form of the rule: its wrong MH proposal has another cause.
 
 usage: exec_lint.py file.s [file.s ...]     exit status 1 if anything is flagged
 """
@@ -23,8 +33,12 @@ FALL = re.compile(r"^; %bb\.\d+:")
 FUNC = re.compile(r"^(_Z\w+):")
 EXECZ = re.compile(r"^\s*s_cbranch_execz\s+(\.LBB[0-9_]+)")
 EXECNZ = re.compile(r"^\s*s_cbranch_execnz\s+")
+ANYBR = re.compile(r"^\s*s_(c?branch\w*|setpc_b64|swappc_b64|endpgm)\b")
 WRITES_EXEC = re.compile(r"^\s*s_\w+\s+exec\b|^\s*s_\w*saveexec")
-RESTORE = re.compile(r"^\s*s_or_b64\s+exec,\s*exec,")
+# EXEC writes that can switch lanes ON (restores); s_and / s_andn2 (and their saveexec forms) only remove lanes
+COPIES_EXEC = re.compile(r"^\s*s_mov_b64\s+s\[\d+:\d+\],\s*exec\b")      # `s_mov sX, exec; s_and sX, sX, ..; s_mov exec, sX` narrows: not a restore
+MOV_TO_EXEC = re.compile(r"^\s*s_mov_b64\s+exec\b")
+ADDS_LANES = re.compile(r"^\s*s_(or|mov|xor|xnor|orn2|cselect|nor|nand)_b64\s+exec\b|^\s*s_(or|xor|orn2|nor|nand|xnor|andn1|orn1)\w*_saveexec")
 
 
 def lint(path):
@@ -51,13 +65,17 @@ def lint(path):
             entry = ln.split(":")[0].strip("; ")
         if entry:
             vec = []
+            copied_exec = False
             j = i + 1
             while j < n:
                 s = lines[j]
-                if LABEL.match(s) or FALL.match(s) or FUNC.match(s) or s.strip().startswith("s_cbranch") or s.strip().startswith("s_branch"):
-                    break
+                if FUNC.match(s) or ANYBR.match(s) or LABEL.match(s):
+                    break          # (a label starts another block with a restore of its own; `; %bb.N` markers are walked through)
+                if COPIES_EXEC.match(s):
+                    copied_exec = True
                 if WRITES_EXEC.match(s):
-                    if RESTORE.match(s) and vec:
+                    restore = ADDS_LANES.match(s) and not (MOV_TO_EXEC.match(s) and copied_exec)
+                    if restore and vec:
                         found.append((func, entry, j + 1, len(vec), vec[0].strip()))
                     break
                 if VEC.match(s):
