@@ -14,7 +14,8 @@ from parity_util import make_sampler
 
 pytestmark = pytest.mark.gpu
 
-CONFIGS = [("funnel10", 65536, 130), ("illnormal100", 16384, 60), ("glmm45", 8192, 40), ("funnel100", 131072, 30)]
+# every configuration crosses the first window closure (draw 50: close_window at full occupancy), funnel-10 the second too
+CONFIGS = [("funnel10", 65536, 130), ("illnormal100", 16384, 60), ("glmm45", 8192, 54), ("funnel100", 131072, 54)]
 FIELDS = ["theta", "rng", "mean", "cov", "eigvecs", "eigvals", "om_m", "om_v", "pca_v", "counters", "acc", "grad_evals"]
 
 
@@ -33,7 +34,7 @@ def test_full_size_population(oracle, name, C, n):
     assert np.all(cnt[:, 0] == n)                                   # _draw
     assert np.all(cnt[:, 1] == cnt[0, 1]) and np.all(cnt[:, 2] == cnt[0, 2]) and np.all(cnt[:, 3] == cnt[0, 3])
     acc = st["acc"]
-    assert 0.2 < acc.mean() <= 1.0 and acc.min() >= 0.0          # (glmm-45 is still in its transient after 40 draws: 0.44)
+    assert 0.2 < acc.mean() <= 1.0 and acc.min() >= 0.0          # (glmm-45 is still in its transient after ~50 draws: ~0.5)
     ge = st["grad_evals"] / n
     assert 40 < ge.mean() < 1200 and ge.min() >= 9                  # >= 1 line + 1 KL evaluation per draw
     # ---- size independence: the same seeds in small launches

@@ -114,6 +114,29 @@ def test_primitives_vs_golden():
 G8 = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "g8_*_w*.npz")))
 
 
+def ill_conditioned(oracle, R, m, init):
+    """How far the ORACLE's own KL fit of record m moves (relative, max over eta) when init[2] changes by one ulp: the
+    conditioning of that record's optimisation problem.  ~1e-14 for an ordinary record, > 1e-4 for the rare fit that walks
+    dozens of evaluations along a flat valley — there no two implementations (not SciPy's own two algebraically equal
+    forms of the BFGS update either) end at the same point."""
+    import ctypes as C
+    L = oracle.lib()
+    dp = C.POINTER(C.c_double)
+    L.klhr_oracle_bfgs.argtypes = [C.c_void_p, dp, C.c_int, dp, C.c_double, dp]
+    c = oracle.Chain(R["stem"], R["data"], seed=0, warmup=R["warmup"], **R["flags"])
+    c.set("theta", R["g"]["theta_before"][m])
+    rho = np.ascontiguousarray(R["g"]["rho"][m])
+    outs = []
+    for nudge in (0, 1):
+        x0 = np.array(init, dtype=np.float64)
+        if nudge:
+            x0[2] = np.nextafter(x0[2], 10.0)
+        out = np.zeros(10)
+        L.klhr_oracle_bfgs(c._h, rho.ctypes.data_as(dp), 4, x0.ctypes.data_as(dp), 1e-3, out.ctypes.data_as(dp))
+        outs.append(out[:4].copy())
+    return float(np.max(np.abs(outs[0] - outs[1]) / (1.0 + np.abs(outs[0]))))
+
+
 @pytest.mark.parametrize("fn", G8)
 def test_teacher_forced_pieces_vs_oracle(oracle, fn):
     """Every record of a golden chain trace becomes one GPU chain: same state before the draw, then each piece of
@@ -162,11 +185,26 @@ def test_teacher_forced_pieces_vs_oracle(oracle, fn):
             np.abs(d[off, col["fun2"]] - o_f2[off]).max()
     sel = same & conv
     err = np.abs(eta - R["eta"]) / (1.0 + np.abs(R["eta"]))
-    # (equal counts do not exclude a line search that took the other side of a Wolfe test on the way: such a record
-    #  still converges to gtol = 1e-3 but to an eta ~1e-4 away — allowed for < 1 % of the records, as against the
-    #  reference below)
+    # Converged fits with identical evaluation counts: eta agrees at the level the kernels deliver (tools/parity_stats.py,
+    # round 2, lane / octet / split kernels alike: worst record 1e-11 on funnel / normal / ill-normal / funnel-100,
+    # 9e-11 on ar1, 3e-9 on glmm-poisson, 2e-7 on earnings whose +-300 clip leaves fits at rounding-noise level), with one
+    # decade of margin.  A record may exceed it only if the ORACLE ITSELF is that sensitive there: its own minimiser moves
+    # by more than 1e-7 when init[2] is changed by one ulp (ill_conditioned below).  g8_funnel10_s7_w1000 holds one such
+    # record (#137: a 34-40 evaluation walk along a flat valley of KL; the oracle lands 2.3e-3 away after a one-ulp nudge,
+    # SciPy-literal and rank-two forms of the same BFGS update 1.0e-3 apart, the reference itself 8e-4 from the oracle).
+    tol_eta = {"earnings": 2e-6, "glmm-poisson": 1e-7}.get(R["stem"], 1e-9)
     worst_o = err[sel].max(axis=1) if sel.any() else np.zeros(1)
-    assert np.mean(worst_o < 2e-6) >= 0.99 and np.all(worst_o < 5e-2), np.sort(worst_o)[-3:]
+    over = np.flatnonzero(sel)[worst_o > tol_eta] if sel.any() else np.zeros(0, dtype=int)
+    assert over.size <= max(1, int(0.01 * sel.sum())), (over, worst_o[worst_o > tol_eta])
+    for m in over:
+        o_rec = o_diag[m]
+        init = [o_rec["init0"], o_rec["init1"], o_rec["init2"], o_rec["init3"]]
+        moved = ill_conditioned(oracle, R, m, init)
+        print(f"{fn}: record {m}: eta differs by {worst_o[np.flatnonzero(sel) == m][0]:.2e} at equal evaluation counts; "
+              f"the oracle's own minimiser moves by {moved:.2e} under a one-ulp change of init[2]")
+        assert moved > 1e-7, (fn, m, moved)
+        # ... and both fits reached the same objective value to the level gtol = 1e-3 implies
+        assert abs(d[m, col["fun2"]] - o_rec["fun2"]) <= 1e-5 * (1.0 + abs(o_rec["fun2"])), (fn, m)
     assert np.all(d[sel, col["status1"]] == 0) and np.all(d[sel, col["status2"]] == 0)
     # Fits that end in a failed line search (status 2; the norm on glmm-poisson, where the +-300 gradient clip makes
     # the gradient inconsistent with the objective) stop at rounding-noise level: WHICH iterate is the last one is
@@ -190,7 +228,20 @@ def test_teacher_forced_pieces_vs_oracle(oracle, fn):
     # (a record whose BFGS sits on a Wolfe/termination decision boundary may stop one step apart: still converged to
     #  gtol = 1e-3, but eta then differs at the 1e-4 level — allowed for < 1 % of records)
     worst = errr[ref_conv].max(axis=1)
-    assert np.mean(worst < 5e-6) >= 0.99 and np.all(worst < 5e-2), np.sort(worst)[-3:]
+    # (the reference's trajectory differs from the oracle's by OpenBLAS / glibc roundings: 5e-6 is the level
+    #  tests/test_oracle_chain.py pins oracle vs reference at; beyond it only records the sensitivity check explains)
+    assert np.mean(worst < 5e-6) >= 0.99, np.sort(worst)[-3:]
+    # the records beyond that level: the device is there because the ORACLE is (its distance to the reference is what
+    # tests/test_oracle_chain.py accounts for) — the device stays within rounding of the oracle, or the record is one of the
+    # ill-conditioned ones classified above
+    gap = (np.abs(R["eta"] - g["eta"][:M]) / (1.0 + np.abs(g["eta"][:M]))).max(axis=1)
+    for m in np.flatnonzero(ref_conv)[worst >= 5e-6]:
+        o_rec = o_diag[m]
+        if not same[m]:
+            continue          # stopped an evaluation apart from the oracle: a decision-boundary record, bounded through its KL value above
+        near_oracle = err[m].max() <= tol_eta and gap[m] >= 0.5 * errr[m].max()
+        assert near_oracle or ill_conditioned(oracle, R, m, [o_rec["init0"], o_rec["init1"], o_rec["init2"], o_rec["init3"]]) > 1e-7, \
+            (fn, m, errr[m].max(), gap[m], err[m].max())
     # ---- a12 MH step from the reference's eta and rho
     s.set("counters", R["cnt_before"])
     s.set("acc", R["acc_before"])
