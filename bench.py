@@ -142,7 +142,9 @@ def run_workload(model, dim, C, steps, warm, repeats, rank, world, device, seed,
     value = total_iters / dt_med
     # ---- per-kernel durations from HIP events on the launch stream (untimed pass; split pipeline: one chain group)
     s.kernel_profiling(True)
-    n_prof = min(steps, profile_iters)
+    # (monolithic kernels run the whole call in one or a few launches: profile a call of the timed length, so that every
+    #  dispatch a rocprofv3 pass sees at the end of the run covers the same number of iterations)
+    n_prof = min(steps, profile_iters) if len(s.kernel_names()) > 1 else steps
     s.step(n_prof, record_draws=True)
     kms, kn = s.kernel_times()
     s.kernel_profiling(False)
