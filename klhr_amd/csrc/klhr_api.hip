@@ -332,7 +332,7 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
     int SL = 3 * D;
     while (SL % 32 != 2) SL++;
     s->S_lane = SL;
-    s->use_lane = (D <= 26) && (((size_t)64 * SL + 624) * 8 <= 64 * 1024);   // + LANE_LDS_EXTRA (klhr_lane_kernel.hpp)
+    s->use_lane = (D <= 26) && (((size_t)64 * SL + 1072) * 8 <= 64 * 1024);   // + LANE_LDS_EXTRA (klhr_lane_kernel.hpp)
     // split-phase pipeline: line-separable targets, any variant but the slice sampler; one [D][64] LDS column block per tile
     const bool split_ok = (cfg->model_id == KLHR_MODEL_FUNNEL || cfg->model_id == KLHR_MODEL_ILL_NORMAL || cfg->model_id == KLHR_MODEL_NORMAL) &&
                           cfg->variant != 3 && ((size_t)D * 16 + 512) * 8 <= 64 * 1024;
@@ -345,7 +345,7 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
     else
     if (const char *kk = getenv("KLHR_KERNEL")) {
         if (!strcmp(kk, "octet")) { s->use_lane = false; s->split = false; }
-        else if (!strcmp(kk, "lane")) { s->split = false; if (((size_t)64 * SL + 624) * 8 <= 64 * 1024) s->use_lane = true; }
+        else if (!strcmp(kk, "lane")) { s->split = false; if (((size_t)64 * SL + 1072) * 8 <= 64 * 1024) s->use_lane = true; }
         else if (!strcmp(kk, "mono")) s->split = false;
         else if (!strcmp(kk, "split")) s->split = split_ok;
     }

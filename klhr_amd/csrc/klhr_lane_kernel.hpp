@@ -206,7 +206,8 @@ __device__ inline void lane_close_window(const KParams &p, long long c, long lon
 
 // extra LDS behind the 64 chain regions (doubles): published trial points [64][4], group partials [64][5],
 // owner table [64] ints, quadrature table asinh(x)[8], w[8]
-constexpr int LANE_XT = 0, LANE_PART = 256, LANE_OWN = 576, LANE_Q = 608, LANE_LDS_EXTRA = 624;
+// (+ the requesters' line sums [64][7] for the closed-form evaluation of the separable targets)
+constexpr int LANE_XT = 0, LANE_PART = 256, LANE_OWN = 576, LANE_Q = 608, LANE_ST = 624, LANE_LDS_EXTRA = 1072;
 
 struct KLScal { double s_, invd, e21, esh; };
 
@@ -333,6 +334,166 @@ __device__ __forceinline__ void lane_eval_line(const KParams &p, const double2 *
 }
 
 // ------------------------------------------------------------------------------------------------
+// Closed-form line evaluation for the separable targets (funnel, ill-normal, normal).  Restricted to a line theta + t*rho
+// their log density is a closed form in t through a handful of per-line sums
+//     sum_i (a_i + t r_i)^2 = A + 2tB + t^2 C,      sum_i (a_i + t r_i) r_i = B + tC         (a = theta or theta/s, r = rho or rho/s),
+// so after ONE O(D) pass per iteration every evaluation of a fit costs O(1) instead of O(D).  The element-wise gradient clip
+// of _logp_grad (klhr_sinh.py:158-161) is inactive whenever max_i |g_i(t)| <= clip, which max|a|, max|r| bound; the rare point
+// where the bound fails (measured on the reference: 1 in 2 000-5 000 KL evaluations) is recomputed by the element-wise loop.
+// Used by this kernel for D <= 26 and by the split-phase pipeline (klhr_split.hpp) above that.
+struct LineStat { double v0, r0, A, B, C, m0, m1; };
+
+#define KLHR_FB(p, f, c) (p).fitbuf[(long long)(f) * (p).fstride + (c)]
+
+__device__ __forceinline__ LineStat load_stat(const KParams &p, long long c) {
+    LineStat s;
+    s.v0 = KLHR_FB(p, F_S0, c); s.r0 = KLHR_FB(p, F_S1, c); s.A = KLHR_FB(p, F_S2, c); s.B = KLHR_FB(p, F_S3, c);
+    s.C = KLHR_FB(p, F_S4, c); s.m0 = KLHR_FB(p, F_S5, c); s.m1 = KLHR_FB(p, F_S6, c);
+    return s;
+}
+
+// log density and clip(grad).rho at theta + t*rho from the line sums.  Returns true when the element-wise clip at +-cl may
+// be active at this point (the caller then recomputes the point with the element-wise loop); CLIP = false: no clipping
+// (logp_grad_rho, klhr_sinh.py:178-180; klhr.py's raw gradient; log-density values of the MH step).
+template <int MODEL, bool CLIP>
+__device__ __forceinline__ bool line_point(const KParams &p, const LineStat &s, double t, double cl, double &logp, double &gdot) {
+    double S = fma(t, fma(t, s.C, 2.0 * s.B), s.A);
+    S = S < 0.0 ? 0.0 : S;                       // a sum of squares: rounding of the closed form may leave -1e-17
+    const double Sr = fma(t, s.C, s.B);
+    if constexpr (MODEL == MODEL_FUNNEL) {
+        const double Da = (double)p.md.n;
+        const double v = fma(t, s.r0, s.v0);
+        const double ev = exp(-v);
+        const double g0 = -v * (1.0 / 9.0) - 0.5 * Da + 0.5 * ev * S;
+        logp = -v * v * (1.0 / 18.0) - 0.5 * Da * v - 0.5 * ev * S;
+        gdot = (CLIP ? clipc(g0, cl) : g0) * s.r0 - ev * Sr;
+        if constexpr (CLIP) return !(ev * (s.m0 + fabs(t) * s.m1) <= cl);
+        return false;
+    } else {
+        logp = -0.5 * S;
+        gdot = -Sr;
+        if constexpr (CLIP) return !(s.m0 + fabs(t) * s.m1 <= cl);
+        return false;
+    }
+}
+
+
+template <int MODEL>
+constexpr bool is_separable() { return MODEL == MODEL_FUNNEL || MODEL == MODEL_ILL_NORMAL || MODEL == MODEL_NORMAL; }
+
+// the line sums of the chain whose (theta_i, rho_i) pairs sit at TR (rho already normalised)
+template <int MODEL>
+__device__ __forceinline__ LineStat lane_line_stats(const KParams &p, const double2 *TR) {
+    LineStat st = {0, 0, 0, 0, 0, 0, 0};
+    const int D = p.D;
+    for (int i = 0; i < D; i++) {
+        const double2 e = TR[i];
+        double a = e.x, r = e.y;
+        if constexpr (MODEL == MODEL_ILL_NORMAL) { const double is = p.md.aux[i]; a = a * is; r = r * is; }
+        if (MODEL == MODEL_FUNNEL && i == 0) { st.v0 = a; st.r0 = r; }
+        else {
+            st.A = fma(a, a, st.A); st.B = fma(a, r, st.B); st.C = fma(r, r, st.C);
+            if constexpr (MODEL == MODEL_ILL_NORMAL) { const double is = p.md.aux[i]; a = a * is; r = r * is; }     // |g_i| = |x_i| / s_i^2
+            st.m0 = fmax(st.m0, fabs(a)); st.m1 = fmax(st.m1, fabs(r));
+            if (a != a || r != r) st.m0 = NAN;
+        }
+    }
+    return st;
+}
+
+#pragma clang fp contract(off)
+// contribution of ONE quadrature node to (KL, dKL/deta) from the line sums: per-node arithmetic identical whoever evaluates
+// it (the chain's own lane, or another lane in the node-shared tail), exact element-wise loop where the clip bound fails
+template <int MODEL, bool SUB>
+__device__ __forceinline__ void cf_node(const KParams &p, const LineStat &st, const double2 *TR, double x0, const KLScal &k, double asx, double w,
+                                        double (&c)[5]) {
+    const double cl = SUB ? p.grad_clip : p.scale_clip;
+    const double a = (asx + k.esh) * k.invd;
+    const double ac = clipc(a, p.scale_clip);
+    const double E = exp(ac), Ei = fast_rcp(E);
+    const double sh = 0.5 * (E - Ei), ch = 0.5 * (E + Ei);
+    const double lch = log_cosh_from_exp(fabs(ac), fmin(E, Ei));
+    const double t = fma(k.s_, sh, x0);
+    double logp, gdot;
+    if (line_point<MODEL, true>(p, st, t, cl, logp, gdot)) {
+        const double t1[1] = {t};
+        double lp1[1], gd1[1];
+        model_eval_nv<MODEL, 1>(p.md, TR, t1, cl, lp1, gd1);
+        logp = lp1[0]; gdot = gd1[0];
+    }
+    kl_node_terms<SUB>(w, a, sh, ch, lch, logp, gdot, k, c);
+}
+// KLHR's objective (klhr.py:109-124): raw gradient, the closed form always applies
+template <int MODEL>
+__device__ __forceinline__ void cf_gauss_node(const KParams &p, const LineStat &st, double m, double s_, double xq, double w, double (&c)[5]) {
+    const double t = fma(s_, xq, m);
+    double logp, gdot;
+    (void)line_point<MODEL, false>(p, st, t, INFINITY, logp, gdot);
+    const double wgr = w * gdot;
+    c[0] = w * logp;
+    c[1] = wgr;
+    c[2] = (wgr * xq) * s_;
+    c[3] = c[4] = 0.0;
+}
+// the chain's own lane: all 8 nodes, summed in the fixed tree ((0+1)+(2+3))+((4+5)+(6+7)) of lane_kl_group.  The four nodes of
+// a half are computed side by side without a branch between them (four independent dependency chains through exp / log cosh:
+// the wavefront is alone on its SIMD and hides latency only through instruction-level parallelism); the rare node whose
+// clip bound fails is patched afterwards with the element-wise loop.  Per node the operations are those of cf_node.
+template <int MODEL, int VARIANT>
+__device__ __forceinline__ void cf_eval_kl(const KParams &p, const LineStat &st, const double2 *TR, const double *xt, const double *qa, const double *qw,
+                                           double &f, double *g) {
+    constexpr bool SUB = VARIANT == VAR_SUB, GAUSS = VARIANT == VAR_GAUSS;
+    const KLScal k = kl_scalars<SUB>(p, xt[1], xt[2], xt[3]);
+    const double sg = GAUSS ? exp(clipc(xt[1], p.scale_clip)) : 0.0;
+    const double cl = SUB ? p.grad_clip : p.scale_clip;
+    double acc5[5] = {0, 0, 0, 0, 0};
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) {
+        double c[4][5];
+        if constexpr (GAUSS) {
+#pragma unroll
+            for (int n = 0; n < 4; n++) cf_gauss_node<MODEL>(p, st, xt[0], sg, qa[4 * h + n], qw[4 * h + n], c[n]);
+        } else {
+            double av[4], sh[4], ch[4], lch[4], t[4], logp[4], gdot[4];
+            bool need[4], any_need = false;
+#pragma unroll
+            for (int n = 0; n < 4; n++) {
+                const double a = (qa[4 * h + n] + k.esh) * k.invd;
+                const double ac = clipc(a, p.scale_clip);
+                const double E = exp(ac), Ei = fast_rcp(E);
+                sh[n] = 0.5 * (E - Ei); ch[n] = 0.5 * (E + Ei);
+                lch[n] = log_cosh_from_exp(fabs(ac), fmin(E, Ei));
+                t[n] = fma(k.s_, sh[n], xt[0]);
+                av[n] = a;
+                need[n] = line_point<MODEL, true>(p, st, t[n], cl, logp[n], gdot[n]);
+                any_need = any_need || need[n];
+            }
+            if (__any(any_need)) {
+#pragma unroll
+                for (int n = 0; n < 4; n++) {
+                    if (need[n]) {
+                        const double t1[1] = {t[n]};
+                        double lp1[1], gd1[1];
+                        model_eval_nv<MODEL, 1>(p.md, TR, t1, cl, lp1, gd1);
+                        logp[n] = lp1[0]; gdot[n] = gd1[0];
+                    }
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < 4; n++) kl_node_terms<SUB>(qw[4 * h + n], av[n], sh[n], ch[n], lch[n], logp[n], gdot[n], k, c[n]);
+        }
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            const double part = (c[0][j] + c[1][j]) + (c[2][j] + c[3][j]);
+            acc5[j] = h == 0 ? part : acc5[j] + part;
+        }
+    }
+    if constexpr (GAUSS) { f = -(acc5[0] + xt[1]); g[0] = -acc5[1]; g[1] = -(acc5[2] + 1.0); g[2] = g[3] = 0.0; }
+    else { f = acc5[0]; g[0] = acc5[1]; g[1] = acc5[2]; g[2] = acc5[3]; g[3] = acc5[4]; }
+}
+#pragma clang fp contract(fast)
+
+// ------------------------------------------------------------------------------------------------
 // OVERRELAX is a compile-time switch: the over-relaxed proposal's code (binomial/beta loops, Phi, Phi^-1) would otherwise
 // sit in the register allocation of every launch (measured: +1.5 KB scratch per lane, -8 % throughput).
 template <int MODEL, bool OVERRELAX, int VARIANT>
@@ -407,6 +568,144 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
         KLHR_STAMP(st_dir);
         // =============================================================== fit
         if (p.phases & PH_FIT) {
+          if constexpr (is_separable<MODEL>()) {
+            // ---- separable targets: closed-form evaluations from the line sums (one O(D) pass), the two stages of fit() as
+            // two loops — the mode search runs opt_advance<N = 1> and never pays for a KL evaluation
+            constexpr bool SUB = VARIANT == VAR_SUB, GAUSS = VARIANT == VAR_GAUSS;
+            constexpr int NFIT = GAUSS ? 2 : (SUB ? 3 : 4);
+            const LineStat st = active ? lane_line_stats<MODEL>(p, TR) : LineStat{0, 0, 0, 0, 0, 0, 0};
+            {
+                double *sl = shx + LANE_ST + lane * 7;
+                sl[0] = st.v0; sl[1] = st.r0; sl[2] = st.A; sl[3] = st.B; sl[4] = st.C; sl[5] = st.m0; sl[6] = st.m1;
+            }
+            Opt o;
+            double fit_n2 = 0, fit_n3 = 0;
+            {
+                double x0v[4] = {0, 0, 0, 0};
+                if (active) {
+                    x0v[0] = rng_std_normal_call(rng) * p.initscale;
+                    if (VARIANT != VAR_GAUSS) {              // klhr.py's fit draws no further normals (klhr.py:134-139)
+                        (void)rng_std_normal_call(rng);
+                        (void)rng_std_normal_call(rng);
+                        fit_n2 = rng_std_normal_call(rng) * p.initscale;
+                        if (VARIANT == VAR_SINH) fit_n3 = rng_std_normal_call(rng) * p.initscale;     // size = 3 for SUBKLHRSINH
+                    }
+                }
+                if (diag && active) dd[KLHR_D_X0] = x0v[0];
+                opt_begin(o, 1, x0v, 1e-5);
+            }
+            int npass = 0, trips = 0;
+            bool done = !active;
+            // ---- stage 1: minimize(logp_grad_rho, x0, BFGS, gtol = 1e-5) (klhr_sinh.py:183-190)
+            for (;;) {
+                if (!done) {
+                    double f = 0, g[4] = {0, 0, 0, 0};
+                    if (opt_cache_hit(o)) { f = o.lf; g[0] = o.lg[0]; }
+                    else {
+                        double lp, gd;
+                        (void)line_point<MODEL, false>(p, st, o.xt[0], INFINITY, lp, gd);
+                        f = -lp; g[0] = -gd;
+                        opt_cache_store(o, f, g);
+                        npass++;
+                    }
+                    opt_advance<false, 1>(o, f, g);
+                    if (o.pc == PC_DONE) done = true;
+                }
+                if (__all(done) || ++trips > KLHR_MAX_PASSES) break;
+            }
+            KLHR_STAMP(st_line);          // (stamps build: the whole mode search, evaluations + optimiser steps)
+            if (active) {
+                if (!done) fit_capped = true;
+                gevals += o.nfev;
+                if (diag) {
+                    dd[KLHR_D_MODE] = o.xk[0]; dd[KLHR_D_HINV1] = o.H[0]; dd[KLHR_D_NFEV1] = o.nfev; dd[KLHR_D_NIT1] = o.k;
+                    dd[KLHR_D_STATUS1] = o.status; dd[KLHR_D_FALLBACKS] = o.fallbacks;
+                }
+                double s1 = o.H[0];
+                s1 = (s1 > 0 ? 1.0 : 0.0) * 0.5 * log(s1);
+                double init[4] = {o.xk[0], s1, fit_n2, fit_n3};
+                if (diag) { dd[KLHR_D_INIT0] = init[0]; dd[KLHR_D_INIT1] = init[1]; dd[KLHR_D_INIT2] = init[2]; dd[KLHR_D_INIT3] = init[3]; }
+                opt_begin(o, NFIT, init, GAUSS ? 1e-5 : 1e-3);
+            }
+            // ---- stage 2: minimize(KL, init, BFGS) (klhr_sinh.py:191-201), node-shared in the tail of the fit (see below)
+            done = !active;
+            trips = 0;
+            for (;;) {
+                double f = 0, g[4] = {0, 0, 0, 0};
+                const bool hit = !done && opt_cache_hit(o);
+                const bool ev4 = !done && !hit;
+                const unsigned long long m4 = __ballot(ev4);
+                const int n4 = __popcll(m4);
+                KLHR_STAMP(st_adv);
+#ifdef KLHR_STAMPS
+                st_trips++;
+                if (n4 > 0) st_kltrips++;
+                if (n4 > 0 && n4 <= 8) st_shtrips++;
+#endif
+                if (n4 > 8) {
+                    if (ev4) cf_eval_kl<MODEL, VARIANT>(p, st, TR, o.xt, shx + LANE_Q, shx + LANE_Q + 8, f, g);
+                    KLHR_STAMP(st_kl);
+                } else if (n4 > 0) {
+                    // at most 8 chains still fitting: each request is served by 8 lanes, one quadrature node each (line sums and
+                    // trial point published in LDS), partial terms back through LDS, summed by the owner in the same fixed tree
+                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m4 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m4, 0u));
+                    if (ev4) {
+                        reinterpret_cast<int *>(shx + LANE_OWN)[rank] = lane;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) shx[LANE_XT + lane * 4 + j] = o.xt[j];
+                    }
+                    KLHR_WAVE_SYNC();
+                    const int r = lane >> 3, node = lane & 7;
+                    if (r < n4) {
+                        const int ow = reinterpret_cast<const int *>(shx + LANE_OWN)[r];
+                        const double x0 = shx[LANE_XT + ow * 4], x1 = shx[LANE_XT + ow * 4 + 1], x2 = shx[LANE_XT + ow * 4 + 2],
+                                     x3 = shx[LANE_XT + ow * 4 + 3];
+                        const double *sl = shx + LANE_ST + ow * 7;
+                        const LineStat so = {sl[0], sl[1], sl[2], sl[3], sl[4], sl[5], sl[6]};
+                        const double2 *TRo = reinterpret_cast<const double2 *>(lds + (size_t)ow * p.S);
+                        double part[5];
+                        if constexpr (GAUSS) cf_gauss_node<MODEL>(p, so, x0, exp(clipc(x1, p.scale_clip)), shx[LANE_Q + node], shx[LANE_Q + 8 + node], part);
+                        else {
+                            const KLScal k = kl_scalars<SUB>(p, x1, x2, x3);
+                            cf_node<MODEL, SUB>(p, so, TRo, x0, k, shx[LANE_Q + node], shx[LANE_Q + 8 + node], part);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 5; j++) shx[LANE_PART + lane * 5 + j] = part[j];
+                    }
+                    KLHR_WAVE_SYNC();
+                    if (ev4) {
+                        const double *pp = shx + LANE_PART + rank * 40;
+                        double r5[5];
+#pragma unroll
+                        for (int j = 0; j < 5; j++)
+                            r5[j] = add_rn(add_rn(add_rn(pp[j], pp[5 + j]), add_rn(pp[10 + j], pp[15 + j])),
+                                              add_rn(add_rn(pp[20 + j], pp[25 + j]), add_rn(pp[30 + j], pp[35 + j])));
+                        if constexpr (GAUSS) { f = -(r5[0] + o.xt[1]); g[0] = -r5[1]; g[1] = -(r5[2] + 1.0); g[2] = g[3] = 0.0; }
+                        else { f = r5[0]; g[0] = r5[1]; g[1] = r5[2]; g[2] = r5[3]; g[3] = r5[4]; }
+                    }
+                    KLHR_STAMP(st_klsh);
+                }
+                if (!done) {
+                    if (hit) { f = o.lf; g[0] = o.lg[0]; g[1] = o.lg[1]; g[2] = o.lg[2]; g[3] = o.lg[3]; }
+                    else { opt_cache_store(o, f, g); npass++; }
+                    opt_advance<false, NFIT>(o, f, g);
+                    if (o.pc == PC_DONE) {
+                        gevals += (long long)o.nfev * 8;
+                        for (int k = 0; k < 4; k++) eta[k] = o.xk[k];
+                        if (diag) {
+                            dd[KLHR_D_NFEV2] = o.nfev; dd[KLHR_D_NIT2] = o.k; dd[KLHR_D_STATUS2] = o.status; dd[KLHR_D_FUN2] = o.old_fval;
+                            dd[KLHR_D_FALLBACKS] += o.fallbacks; dd[KLHR_D_PASSES] = npass;
+                        }
+                        done = true;
+                    }
+                }
+                if (__all(done) || ++trips > KLHR_MAX_PASSES) break;
+            }
+            if (!done) { fit_capped = true; for (int k = 0; k < 4; k++) eta[k] = o.xk[k]; }
+            if (active && (p.flags & FLAG_DIAG)) {
+                for (int k = 0; k < 4; k++) p.d_eta[c * 4 + k] = eta[k];
+            }
+          } else {
             Opt o;
             // fit() consumes exactly five normals — x0, then size-4 init of which the first two are discarded
             // (klhr_sinh.py:184,191-193) — and nothing in between touches the generator, so all five are drawn here,
@@ -542,6 +841,7 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
             if (active && (p.flags & FLAG_DIAG)) {
                 for (int k = 0; k < 4; k++) p.d_eta[c * 4 + k] = eta[k];
             }
+          }
         } else if (active) {
             for (int k = 0; k < 4; k++) eta[k] = p.d_eta[c * 4 + k];
         }
@@ -549,7 +849,15 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
         // =============================================================== KL / line probes
         if ((p.phases & (PH_KL | PH_LINE)) && active) {
             double f, g[4];
-            if (p.phases & PH_KL) {
+            if constexpr (is_separable<MODEL>()) {
+                const LineStat stp = lane_line_stats<MODEL>(p, TR);
+                if (p.phases & PH_KL) cf_eval_kl<MODEL, VARIANT>(p, stp, TR, eta, shx + LANE_Q, shx + LANE_Q + 8, f, g);
+                else {
+                    double lp, gd;
+                    (void)line_point<MODEL, false>(p, stp, eta[0], INFINITY, lp, gd);
+                    f = -lp; g[0] = -gd; g[1] = g[2] = g[3] = 0.0;
+                }
+            } else if (p.phases & PH_KL) {
                 if constexpr (VARIANT == VAR_GAUSS) lane_eval_kl_gauss<MODEL>(p, TR, eta, f, g);
                 else lane_eval_kl<MODEL, VARIANT == VAR_SUB>(p, TR, eta, f, g);
             } else lane_eval_line<MODEL>(p, TR, eta[0], f, g);
@@ -566,8 +874,16 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
             else if constexpr (VARIANT == VAR_GAUSS) zp = gauss_zp<false>(rng, eta, Kc, p.scale_clip);
             else if constexpr (OVERRELAX) { const ZpOut zo = overrelaxed_zp_call(rng, eta[0], eta[1], eta[2], eta[3], p.K, p.tol, p.scale_clip, VARIANT == VAR_SUB); zp = zo.zp; rng = zo.rng; }
             else zp = sa_T(rng_std_normal_call(rng), eta, p.tol, p.scale_clip, VARIANT == VAR_SUB);
-            double t2[2] = {zp, 0.0}, lp2[2], gd2[2];
-            model_eval_nv<MODEL, 2>(p.md, TR, t2, INFINITY, lp2, gd2);
+            double lp2[2], gd2[2];
+            if constexpr (is_separable<MODEL>()) {
+                // (the line sums of this iteration's direction: recomputed here rather than kept in registers across the fit)
+                const LineStat stm = lane_line_stats<MODEL>(p, TR);
+                (void)line_point<MODEL, false>(p, stm, zp, INFINITY, lp2[0], gd2[0]);
+                (void)line_point<MODEL, false>(p, stm, 0.0, INFINITY, lp2[1], gd2[1]);
+            } else {
+                double t2[2] = {zp, 0.0};
+                model_eval_nv<MODEL, 2>(p.md, TR, t2, INFINITY, lp2, gd2);
+            }
             double r = lp2[0];
             r -= lp2[1];
             if constexpr (VARIANT == VAR_GAUSS) {

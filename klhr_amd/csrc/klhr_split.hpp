@@ -29,42 +29,7 @@
 namespace klhr {
 
 // (per-chain fit record F_*: klhr_kernels.hpp)
-struct LineStat { double v0, r0, A, B, C, m0, m1; };
-
-#define KLHR_FB(p, f, c) (p).fitbuf[(long long)(f) * (p).fstride + (c)]
-
-__device__ __forceinline__ LineStat load_stat(const KParams &p, long long c) {
-    LineStat s;
-    s.v0 = KLHR_FB(p, F_S0, c); s.r0 = KLHR_FB(p, F_S1, c); s.A = KLHR_FB(p, F_S2, c); s.B = KLHR_FB(p, F_S3, c);
-    s.C = KLHR_FB(p, F_S4, c); s.m0 = KLHR_FB(p, F_S5, c); s.m1 = KLHR_FB(p, F_S6, c);
-    return s;
-}
-
-// log density and clip(grad).rho at theta + t*rho from the line sums.  Returns true when the element-wise clip at +-cl may
-// be active at this point (the caller then recomputes the point with exact_points4); CLIP = false: no clipping
-// (logp_grad_rho, klhr_sinh.py:178-180; klhr.py's raw gradient; log-density values of the MH step).
-template <int MODEL, bool CLIP>
-__device__ __forceinline__ bool line_point(const KParams &p, const LineStat &s, double t, double cl, double &logp, double &gdot) {
-    double S = fma(t, fma(t, s.C, 2.0 * s.B), s.A);
-    S = S < 0.0 ? 0.0 : S;                       // a sum of squares: rounding of the closed form may leave -1e-17
-    const double Sr = fma(t, s.C, s.B);
-    if constexpr (MODEL == MODEL_FUNNEL) {
-        const double Da = (double)p.md.n;
-        const double v = fma(t, s.r0, s.v0);
-        const double ev = exp(-v);
-        const double g0 = -v * (1.0 / 9.0) - 0.5 * Da + 0.5 * ev * S;
-        logp = -v * v * (1.0 / 18.0) - 0.5 * Da * v - 0.5 * ev * S;
-        gdot = (CLIP ? clipc(g0, cl) : g0) * s.r0 - ev * Sr;
-        if constexpr (CLIP) return !(ev * (s.m0 + fabs(t) * s.m1) <= cl);
-        return false;
-    } else {
-        logp = -0.5 * S;
-        gdot = -Sr;
-        if constexpr (CLIP) return !(s.m0 + fabs(t) * s.m1 <= cl);
-        return false;
-    }
-}
-
+// (LineStat, line_point: klhr_lane_kernel.hpp — the lane-per-chain kernel evaluates the same closed forms)
 // The exact element-wise evaluation of four points of one chain's line (model_eval's arithmetic, in index order), from
 // the tiled theta / direction rows in HBM: the rare path behind line_point's clip bound.  Out of line, by value.
 struct Pts4 { double lp[4], gd[4]; };
