@@ -591,7 +591,10 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
     const uint64_t *zki = nullptr;
     {
         const int naux = MODEL == MODEL_GLMM_POISSON ? 4 * p.md.n : (MODEL == MODEL_ILL_NORMAL ? D : 0);
-        if (naux > 0) {
+        // (unconditional for the two targets that have model data: a pointer that may be global OR LDS is a generic pointer —
+        //  every read of the staged table was a flat_load going through the vector-memory path, 17 k per wavefront-iteration
+        //  on glmm-poisson; derived from `lds` on every path it is provably LDS and the reads are ds_read)
+        if constexpr (MODEL == MODEL_GLMM_POISSON || MODEL == MODEL_ILL_NORMAL) {
             double *aux_l = lds + (size_t)8 * p.S;
             for (int i = lane; i < naux; i += 64) aux_l[i] = p.md.aux[i];
             md.aux = aux_l;

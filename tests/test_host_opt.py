@@ -103,3 +103,24 @@ def test_rank_two_update_agrees_with_scipy_form(oracle, harness):
             worst = max(worst, float(np.max(np.abs(a[:4] - b[:4]) / (1 + np.abs(a[:4])))))
     assert same >= 0.97 * N, same
     assert worst < 1e-8, worst
+
+
+def test_dimension_specialised_optimiser_equals_padded_form(oracle, harness):
+    """opt_advance<OUTLINE, N> (round 2: the mode search runs N = 1, the KL fits N = 4 | 3 | 2) against the zero-padded
+    N = 4 form every problem ran through in round 1: identical x, value, Hessian entry, counts and status, bit for bit, on the
+    golden funnel records and on pathological starts (padded coordinates only ever added exact zeros)."""
+    H, _ = harness
+    dp = C.POINTER(C.c_double)
+    H.klhr_harness_bfgs_n.argtypes = [C.c_void_p, dp, C.c_int, dp, C.c_double, dp]
+    g = golden("g8_funnel10_s0_w100.npz")
+    stem, data = model_spec("funnel10")
+    c = oracle.Chain(stem, data, seed=0, warmup=100)
+    rng = np.random.default_rng(11)
+    for m in range(400):
+        c.set("theta", g["theta_before"][m] if m % 4 else rng.normal(size=10) * 2.5)
+        rho = np.ascontiguousarray(g["rho"][m])
+        for n, x0, gtol in ((1, np.array([g["x0"][m] * (1 if m % 5 else 30)]), 1e-5), (4, np.ascontiguousarray(g["init"][m]), 1e-3)):
+            a, b = np.zeros(10), np.zeros(10)
+            H.klhr_harness_bfgs(c._h, rho.ctypes.data_as(dp), n, x0.ctypes.data_as(dp), gtol, a.ctypes.data_as(dp))
+            H.klhr_harness_bfgs_n(c._h, rho.ctypes.data_as(dp), n, x0.ctypes.data_as(dp), gtol, b.ctypes.data_as(dp))
+            assert np.array_equal(a, b, equal_nan=True), (m, n, a, b)
