@@ -191,6 +191,69 @@ __device__ __forceinline__ void model_eval(const ModelData &md, XR xr, double cl
 #ifndef KLHR_GLMM_BLK
 #define KLHR_GLMM_BLK 4          // years of glmm-poisson evaluated together (independent exp chains)
 #endif
+// exp() of U values in lock step: ocml's double-precision exp (argument reduction by ln2 in two pieces, degree-11 polynomial,
+// ldexp, the two range selects), operation for operation — the results are bit-identical to exp() — but written over the
+// block, so that every polynomial coefficient is ONE operand shared by the U chains (a scalar-register pair or a single
+// register pair), instead of being re-materialised per call the way the inlined library code was inside the glmm year
+// loop (15 v_mov per exp on top of its 27 instructions).
+template <int U>
+__device__ __forceinline__ void exp_block(const double (&x)[U], double (&y)[U]) {
+    double dn[U], r[U], q[U];
+#pragma unroll
+    for (int k = 0; k < U; k++) dn[k] = __builtin_rint(x[k] * 0x1.71547652b82fep+0);
+#pragma unroll
+    for (int k = 0; k < U; k++) r[k] = __builtin_fma(dn[k], -0x1.62e42fefa39efp-1, x[k]);
+#pragma unroll
+    for (int k = 0; k < U; k++) r[k] = __builtin_fma(dn[k], -0x1.abc9e3b39803fp-56, r[k]);
+#pragma unroll
+    for (int k = 0; k < U; k++) q[k] = __builtin_fma(r[k], 0x1.ade156a5dcb37p-26, 0x1.28af3fca7ab0cp-22);
+#define KLHR_EXP_STEP(C) _Pragma("unroll") for (int k = 0; k < U; k++) q[k] = __builtin_fma(r[k], q[k], C);
+    KLHR_EXP_STEP(0x1.71dee623fde64p-19) KLHR_EXP_STEP(0x1.a01997c89e6b0p-16) KLHR_EXP_STEP(0x1.a01a014761f6ep-13)
+    KLHR_EXP_STEP(0x1.6c16c1852b7b0p-10) KLHR_EXP_STEP(0x1.1111111122322p-7) KLHR_EXP_STEP(0x1.55555555502a1p-5)
+    KLHR_EXP_STEP(0x1.5555555555511p-3) KLHR_EXP_STEP(0x1.000000000000bp-1) KLHR_EXP_STEP(1.0) KLHR_EXP_STEP(1.0)
+#undef KLHR_EXP_STEP
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+        double z = __builtin_amdgcn_ldexp(q[k], (int)dn[k]);
+        z = x[k] > 1024.0 ? __builtin_inf() : z;
+        y[k] = x[k] < -1075.0 ? 0.0 : z;
+    }
+}
+
+// U years of glmm-poisson (indices first, first + step, ...) at the point theta + t rho: model_eval's arithmetic per year,
+// accumulated in index order; no bounds checks — callers take whole blocks, then single years, and set gd to NaN when
+// sawnan (np.clip passes a NaN gradient component through, and one NaN term makes the sum NaN).
+struct GlmmSums { double sr, s1, s2, s3, sre, see, lik, gd; bool sawnan; };
+template <int U>
+__device__ __forceinline__ void glmm_years(const double2 *TR, const double *x1, const double *x2, const double *x3, const double *Cn,
+                                           int first, int step, double t, double alpha, double b0, double b1, double b2,
+                                           double sigma, double cl, GlmmSums &a) {
+    double2 e2[U];
+    double xa[U], xb[U], xc[U], cc[U], e[U], eta[U], mu[U];
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+        const int i = first + k * step;
+        e2[k] = TR[5 + i]; xa[k] = x1[i]; xb[k] = x2[i]; xc[k] = x3[i]; cc[k] = Cn[i];
+    }
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+        e[k] = fma(t, e2[k].y, e2[k].x);
+        eta[k] = alpha + xa[k] * b0 + xb[k] * b1 + xc[k] * b2 + sigma * e[k];
+    }
+    exp_block<U>(eta, mu);
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+        const double r = cc[k] - mu[k];
+        a.lik += cc[k] * eta[k] - mu[k];
+        a.see += e[k] * e[k];
+        a.sr += r; a.s1 += xa[k] * r; a.s2 += xb[k] * r; a.s3 += xc[k] * r;
+        a.sre += r * e[k];
+        const double ge = -e[k] + sigma * r;
+        a.sawnan = a.sawnan || (ge != ge);                 // v_max / v_min drop NaNs: np.clip's NaN is restored by the callers
+        a.gd += fmin(fmax(ge, -cl), cl) * e2[k].y;
+    }
+}
+
 template <int B>
 __device__ __forceinline__ void tr_load_block(const double2 *TR, int i0, int D, double2 (&r)[B]) {
     if (i0 + B <= D) {          // whole block inside the row: immediate offsets, no index arithmetic
@@ -272,35 +335,13 @@ __device__ __forceinline__ void model_eval_tr(const ModelData &md, const double2
         double lp = -alpha * alpha * (1.0 / 50.0);
         lp -= b0 * b0 * (1.0 / 50.0); lp -= b1 * b1 * (1.0 / 50.0); lp -= b2 * b2 * (1.0 / 50.0);
         lp -= 0.5 * ell * ell;
-        double sr = 0, s1 = 0, s2 = 0, s3 = 0, sre = 0, see = 0, lik = 0, gd = 0;
+        GlmmSums a = {0, 0, 0, 0, 0, 0, 0, 0, false};
         constexpr int U = KLHR_GLMM_BLK;
-        for (int i0 = 0; i0 < n; i0 += U) {
-            double2 e2[U];
-            double xa[U], xb[U], xc[U], cc[U], e[U], eta[U], mu[U];
-#pragma unroll
-            for (int k = 0; k < U; k++) {
-                const int i = i0 + k < n ? i0 + k : n - 1;
-                e2[k] = TR[5 + i]; xa[k] = x1[i]; xb[k] = x2[i]; xc[k] = x3[i]; cc[k] = Cn[i];
-            }
-#pragma unroll
-            for (int k = 0; k < U; k++) {
-                e[k] = fma(t, e2[k].y, e2[k].x);
-                eta[k] = alpha + xa[k] * b0 + xb[k] * b1 + xc[k] * b2 + sigma * e[k];
-                mu[k] = exp(eta[k]);
-            }
-#pragma unroll
-            for (int k = 0; k < U; k++) {
-                if (i0 + k < n) {
-                    const double r = cc[k] - mu[k];
-                    lik += cc[k] * eta[k] - mu[k];
-                    see += e[k] * e[k];
-                    sr += r; s1 += xa[k] * r; s2 += xb[k] * r; s3 += xc[k] * r;
-                    sre += r * e[k];
-                    const double ge = -e[k] + sigma * r;
-                    gd += clipc(ge, cl) * e2[k].y;
-                }
-            }
-        }
+        int i0 = 0;
+        for (; i0 + U <= n; i0 += U) glmm_years<U>(TR, x1, x2, x3, Cn, i0, 1, t, alpha, b0, b1, b2, sigma, cl, a);
+        for (; i0 < n; i0++) glmm_years<1>(TR, x1, x2, x3, Cn, i0, 1, t, alpha, b0, b1, b2, sigma, cl, a);
+        const double sr = a.sr, s1 = a.s1, s2 = a.s2, s3 = a.s3, sre = a.sre, see = a.see, lik = a.lik;
+        double gd = a.sawnan ? NAN : a.gd;
         lp += -0.5 * see + lik;
         const double g0 = -alpha * (1.0 / 25.0) + sr, g1 = -b0 * (1.0 / 25.0) + s1, g2 = -b1 * (1.0 / 25.0) + s2, g3 = -b2 * (1.0 / 25.0) + s3;
         const double g4 = -ell + sigma * sre;
@@ -361,34 +402,12 @@ __device__ __forceinline__ void model_eval_split(const ModelData &md, const doub
         const double2 ea = TR[0], eb0 = TR[1], eb1 = TR[2], eb2 = TR[3], el = TR[4];
         const double alpha = fma(t, ea.y, ea.x), b0 = fma(t, eb0.y, eb0.x), b1 = fma(t, eb1.y, eb1.x), b2 = fma(t, eb2.y, eb2.x);
         const double ell = fma(t, el.y, el.x), sigma = exp(ell);
-        double sr = 0, s1 = 0, s2 = 0, s3 = 0, sre = 0, see = 0, lik = 0, gd = 0;
+        GlmmSums a = {0, 0, 0, 0, 0, 0, 0, 0, false};
         constexpr int U = KLHR_GLMM_BLK;
-        for (int i0 = l8; i0 < n; i0 += 8 * U) {       // this lane's years, U at a time (independent exp chains)
-            double2 e2[U];
-            double xa[U], xb[U], xc[U], cc[U], e[U], eta[U], mu[U];
-#pragma unroll
-            for (int k = 0; k < U; k++) {
-                const int i = i0 + 8 * k < n ? i0 + 8 * k : i0;
-                e2[k] = TR[5 + i]; xa[k] = x1[i]; xb[k] = x2[i]; xc[k] = x3[i]; cc[k] = Cn[i];
-            }
-#pragma unroll
-            for (int k = 0; k < U; k++) {
-                e[k] = fma(t, e2[k].y, e2[k].x);
-                eta[k] = alpha + xa[k] * b0 + xb[k] * b1 + xc[k] * b2 + sigma * e[k];
-                mu[k] = exp(eta[k]);
-            }
-#pragma unroll
-            for (int k = 0; k < U; k++) {
-                if (i0 + 8 * k < n) {
-                    const double r = cc[k] - mu[k];
-                    lik += cc[k] * eta[k] - mu[k];
-                    see += e[k] * e[k];
-                    sr += r; s1 += xa[k] * r; s2 += xb[k] * r; s3 += xc[k] * r;
-                    sre += r * e[k];
-                    gd += clipc(-e[k] + sigma * r, cl) * e2[k].y;
-                }
-            }
-        }
+        int i0 = l8;                                   // this lane's years l8, l8 + 8, ...: whole blocks, then single years
+        for (; i0 + 8 * (U - 1) < n; i0 += 8 * U) glmm_years<U>(TR, x1, x2, x3, Cn, i0, 8, t, alpha, b0, b1, b2, sigma, cl, a);
+        for (; i0 < n; i0 += 8) glmm_years<1>(TR, x1, x2, x3, Cn, i0, 8, t, alpha, b0, b1, b2, sigma, cl, a);
+        double sr = a.sr, s1 = a.s1, s2 = a.s2, s3 = a.s3, sre = a.sre, see = a.see, lik = a.lik, gd = a.sawnan ? NAN : a.gd;
         sr = sum8(sr); s1 = sum8(s1); s2 = sum8(s2); s3 = sum8(s3); sre = sum8(sre); see = sum8(see); lik = sum8(lik); gd = sum8(gd);
         double lp = -alpha * alpha * (1.0 / 50.0);
         lp -= b0 * b0 * (1.0 / 50.0); lp -= b1 * b1 * (1.0 / 50.0); lp -= b2 * b2 * (1.0 / 50.0);
