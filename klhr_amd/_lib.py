@@ -215,8 +215,8 @@ class Sampler:
         self._ck(self._L.klhr_reserve_draws(self._h, int(n)), "klhr_reserve_draws")
 
     def kernel_name(self):
-        return {0: "klhr_iter_kernel", 1: "klhr_lane_kernel", 2: "klhr_stream_kernel+klhr_fit1_kernel+klhr_fit2_kernel"}[
-            self._L.klhr_kernel_variant(self._h)]
+        return {0: "klhr_iter_kernel", 1: "klhr_lane_kernel", 2: "klhr_stream_kernel+klhr_fit1_kernel+klhr_fit2_kernel",
+                3: "klhr_stream_kernel+klhr_fitn_kernel"}[self._L.klhr_kernel_variant(self._h)]
 
     def draws(self, first=0, n=None, total=None):
         n = int(n)
@@ -235,8 +235,8 @@ class Sampler:
         return [ms[i] for i in range(3)], [n[i] for i in range(3)]
 
     def kernel_names(self):
-        return {0: ["klhr_iter_kernel"], 1: ["klhr_lane_kernel"], 2: ["klhr_stream_kernel", "klhr_fit1_kernel", "klhr_fit2_kernel"]}[
-            self._L.klhr_kernel_variant(self._h)]
+        return {0: ["klhr_iter_kernel"], 1: ["klhr_lane_kernel"], 2: ["klhr_stream_kernel", "klhr_fit1_kernel", "klhr_fit2_kernel"],
+                3: ["klhr_stream_kernel", "(none)", "klhr_fitn_kernel"]}[self._L.klhr_kernel_variant(self._h)]
 
     def timing(self):
         ms = C.c_double()

@@ -99,6 +99,7 @@ struct klhr_sampler {
     void *comm = nullptr;
     int comm_rank = 0, comm_world = 0;
     bool async_ok = false;       // klhr_step lets chains progress asynchronously (split pipeline)
+    bool fitn = false;           // split pipeline: both fit stages in the node-parallel kernel (few chains: klhr_fitn_kernel)
     unsigned int *h_pend = nullptr;      // pinned host copy of the groups' pending-chain counters
     bool profile = false;
     std::vector<hipEvent_t> pev;
@@ -208,7 +209,7 @@ extern "C" int klhr_device_count(void) {
 extern "C" const char *klhr_last_error(const klhr_sampler *s) { return s ? s->err.c_str() : g_create_err.c_str(); }
 extern "C" int klhr_dim(const klhr_sampler *s) { return s ? s->D : KLHR_ERR_ARG; }
 extern "C" int klhr_chains(const klhr_sampler *s) { return s ? s->C : KLHR_ERR_ARG; }
-extern "C" int klhr_kernel_variant(const klhr_sampler *s) { return s ? (s->split ? 2 : (s->use_lane ? 1 : 0)) : KLHR_ERR_ARG; }
+extern "C" int klhr_kernel_variant(const klhr_sampler *s) { return s ? (s->split ? (s->fitn ? 3 : 2) : (s->use_lane ? 1 : 0)) : KLHR_ERR_ARG; }
 
 // ---- host <-> device copies of [C][W] state arrays: the host side is always chain-major (the NumPy layout); the device
 // side is tiled [tile][w][64 lanes] for handles of the split pipeline
@@ -396,6 +397,11 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
         k.async_mode = 0; k.budget1 = 12; k.budget2 = 28;
         s->async_ok = false;
         if (const char *e = getenv("KLHR_ASYNC")) s->async_ok = atoi(e) != 0;
+        // few chains: the fit's latency (its slowest chain's sequence of passes) is the launch's duration — 8 lanes per chain
+        // shorten the pass (klhr_split.hpp: klhr_fitn_kernel).  Measured, ill-normal-100, both stages: 16 384 chains 77 us against
+        // 159, 32 768: 118 / 171, 65 536: 204 / 183, funnel-100 x 131 072: 952 / 676 — from 65 536 chains on lane = chain has the throughput
+        s->fitn = C <= 32768;
+        if (const char *e = getenv("KLHR_FITN")) s->fitn = atoi(e) != 0;
         if (const char *e = getenv("KLHR_FIT_BUDGET1")) { const int v = atoi(e); if (v >= 1) k.budget1 = v; }
         if (const char *e = getenv("KLHR_FIT_BUDGET2")) { const int v = atoi(e); if (v >= 1) k.budget2 = v; }
         // Chain groups of klhr_step: the streaming kernel is bound by memory, the fit kernels by the fp64 ALUs; with the chains
@@ -414,6 +420,8 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
         size_t nw = zb ? cap / zb : 4;
         k.stream_waves = (int)(nw < 1 ? 1 : (nw > 4 ? 4 : nw));
         if (const char *e = getenv("KLHR_STREAM_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 4) k.stream_waves = v; }
+        k.fit_lanes = 0;           // 0: chosen per launch from the chain count of the launch (klhr_split.hip)
+        if (const char *e = getenv("KLHR_FIT_LANES")) { const int v = atoi(e); if (v == 8 || v == 16 || v == 32 || v == 64) k.fit_lanes = v; }
     }
     k.flags = (cfg->scale_dir_cov ? FLAG_SCALE_DIR_COV : 0) | (cfg->eigen_method_one ? FLAG_EIGEN_ONE : 0) |
               (cfg->overrelaxed ? FLAG_OVERRELAXED : 0);
@@ -629,9 +637,9 @@ static int run_phases(klhr_sampler *s, int phases, int64_t n_iters, int record_d
                 if (do_tail || do_head) launch_split(s, kp, 0, do_tail, do_head, st);
                 if (mark((int)it * 4 + 1)) return KLHR_ERR_HIP;
                 if (it < n_iters && (phases & PH_FIT)) {
-                    launch_split(s, kp, 1, 0, 0, st);
+                    if (!s->fitn) launch_split(s, kp, 1, 0, 0, st);
                     if (mark((int)it * 4 + 2)) return KLHR_ERR_HIP;
-                    launch_split(s, kp, 2, 0, 0, st);
+                    launch_split(s, kp, s->fitn ? 4 : 2, 0, 0, st);
                     if (mark((int)it * 4 + 3)) return KLHR_ERR_HIP;
                 }
                 if (it < n_iters && (phases & (PH_KL | PH_LINE))) {
@@ -733,6 +741,7 @@ extern "C" int klhr_last_kernel_times(klhr_sampler *s, double ms3[3], int n3[3])
             HIPCHECK(s, hipEventElapsedTime(&ms, s->pev[it * 4 + k], s->pev[it * 4 + k + 1]));
             tot[k] += ms; n3[k] += 1;
         }
+    if (s->fitn) { tot[1] = 0; n3[1] = 0; }          // (the node-parallel kernel runs both stages: slot 2)
     for (int k = 0; k < 3; k++) ms3[k] = n3[k] ? tot[k] / n3[k] : 0;
     return KLHR_OK;
 }

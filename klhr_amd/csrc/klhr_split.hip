@@ -14,9 +14,14 @@
 namespace klhr {
 
 template <int MODEL>
-static void launch_split_model(const KParams &kp, int what, bool overrelaxed, int do_tail, int do_head, hipStream_t stream) {
+static void launch_split_model(const KParams &kp0, int what, bool overrelaxed, int do_tail, int do_head, hipStream_t stream) {
     constexpr int V = KLHR_VARIANT;
-    const unsigned tiles = (unsigned)((kp.C + 63) / 64);          // fit / probe kernels: 64 chains per wavefront
+    // fit / probe kernels: lane = chain, fit_lanes chains per wavefront (KLHR_FIT_LANES; 64).  Measured at 16 384 chains: 64, 32
+    // and 16 chains per wavefront take the same time (a launch lasts as long as its slowest chain's sequence of passes, on
+    // however many SIMDs), 8 take twice as long — few chains go to the node-parallel kernel (what == 4) instead.
+    KParams kp = kp0;
+    if (kp.fit_lanes <= 0) kp.fit_lanes = 64;
+    const unsigned tiles = (unsigned)((kp.C + kp.fit_lanes - 1) / kp.fit_lanes);
     const unsigned stiles = (unsigned)(kp.Cpad / kp.tw);          // streaming kernel: one wavefront per tile of tw chains,
     const unsigned sgroups = (stiles + kp.stream_waves - 1) / kp.stream_waves;      // stream_waves tiles per workgroup
     const dim3 block(64), sblock(64 * kp.stream_waves);
@@ -25,6 +30,8 @@ static void launch_split_model(const KParams &kp, int what, bool overrelaxed, in
         hipLaunchKernelGGL((klhr_fit1_kernel<MODEL>), dim3(fitgrid), block, 0, stream, kp);
     } else if (what == 2) {
         hipLaunchKernelGGL((klhr_fit2_kernel<MODEL, V>), dim3(fitgrid), block, 0, stream, kp);
+    } else if (what == 4) {
+        hipLaunchKernelGGL((klhr_fitn_kernel<MODEL, V>), dim3((unsigned)((kp.C + 7) / 8)), block, 0, stream, kp);
     } else if (what == 3) {
         hipLaunchKernelGGL((klhr_probe_kernel<MODEL, V>), dim3(tiles), block, 0, stream, kp);
     } else {
@@ -40,7 +47,7 @@ static void launch_split_model(const KParams &kp, int what, bool overrelaxed, in
     }
 }
 
-// what: 0 streaming kernel (do_tail / do_head), 1 mode search, 2 KL fit, 3 KL / line probe
+// what: 0 streaming kernel (do_tail / do_head), 1 mode search, 2 KL fit, 3 KL / line probe, 4 both fit stages node-parallel
 void KLHR_CAT2(launch_split_v, KLHR_VARIANT)(const KParams &kp, int model_id, int what, bool overrelaxed, int do_tail, int do_head, hipStream_t stream) {
     switch (model_id) {
     case KLHR_MODEL_FUNNEL: launch_split_model<MODEL_FUNNEL>(kp, what, overrelaxed, do_tail, do_head, stream); break;

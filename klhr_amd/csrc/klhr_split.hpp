@@ -182,8 +182,8 @@ __device__ __forceinline__ void opt_restore(const KParams &p, long long c, Opt &
 template <int MODEL>
 __global__ __launch_bounds__(64) void klhr_fit1_kernel(const KParams p) {
     const int lane = threadIdx.x & 63;
-    const long long task = (long long)blockIdx.x * 64 + lane;
-    if (task >= p.C) return;
+    const long long task = (long long)blockIdx.x * p.fit_lanes + lane;
+    if (lane >= p.fit_lanes || task >= p.C) return;
     const bool diag = (p.flags & FLAG_DIAG) != 0;
     int ph = p.async_mode ? p.phase[task] : PHS_FIT1;
     if (ph != PHS_FIT1 && ph != PHS_FIT1_RESUME) return;
@@ -243,8 +243,8 @@ template <int MODEL, int VARIANT>
 __global__ __launch_bounds__(64) void klhr_fit2_kernel(const KParams p) {
     constexpr int N = VARIANT == VAR_GAUSS ? 2 : (VARIANT == VAR_SUB ? 3 : 4);
     const int lane = threadIdx.x & 63;
-    const long long task = (long long)blockIdx.x * 64 + lane;
-    if (task >= p.C) return;
+    const long long task = (long long)blockIdx.x * p.fit_lanes + lane;
+    if (lane >= p.fit_lanes || task >= p.C) return;
     const bool diag = (p.flags & FLAG_DIAG) != 0;
     int ph = p.async_mode ? p.phase[task] : PHS_FIT2;
     if (ph != PHS_FIT2 && ph != PHS_FIT2_RESUME) return;
@@ -301,11 +301,151 @@ __global__ __launch_bounds__(64) void klhr_fit2_kernel(const KParams p) {
     if (p.async_mode) p.phase[task] = ph;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Node-parallel fit for FEW chains (klhr_split.hip: at most 16 384 per launch): both stages of fit() in one kernel, 8 lanes per
+// chain.  With lane = chain a launch lasts as long as its slowest chain's sequence of passes, however few chains there are,
+// and a KL pass is 8 quadrature nodes one after the other.  Here lane l8 of a chain's octet evaluates node l8 and a butterfly
+// (grp_sum8: the tree ((0+1)+(2+3))+((4+5)+(6+7)) of split_kl_group / split_eval_kl, additions commuted) hands every lane the
+// same sums; the optimiser state is replicated in the 8 lanes (identical inputs, identical steps).  A wavefront holds 8 chains,
+// not 64: fewer optimiser states to serialise per pass.  Per node and per step the arithmetic is that of klhr_fit1_kernel /
+// klhr_fit2_kernel: the two forms return the same bits (tests/test_gpu_parity.py compares them).
+#pragma clang fp contract(off)
+template <int MODEL, int VARIANT>
+__device__ __forceinline__ void node_eval_kl(const KParams &p, const LineStat &st, long long c, double nn, const double *xt, double q_a, double q_x,
+                                             double q_w, double &f, double *g) {
+    double cc[5];
+    if constexpr (VARIANT == VAR_GAUSS) {
+        const double sg = exp(clipc(xt[1], p.scale_clip));
+        const double t = fma(sg, q_x, xt[0]);
+        double logp, gdot;
+        (void)line_point<MODEL, false>(p, st, t, INFINITY, logp, gdot);
+        const double wgr = q_w * gdot;
+        cc[0] = q_w * logp; cc[1] = wgr; cc[2] = (wgr * q_x) * sg; cc[3] = cc[4] = 0.0;
+        const double a0 = grp_sum8(cc[0]), a1 = grp_sum8(cc[1]), a2 = grp_sum8(cc[2]);
+        f = -(a0 + xt[1]); g[0] = -a1; g[1] = -(a2 + 1.0); g[2] = g[3] = 0.0;
+    } else {
+        constexpr bool SUB = VARIANT == VAR_SUB;
+        const KLScal k = kl_scalars<SUB>(p, xt[1], xt[2], xt[3]);
+        const double cl = SUB ? p.grad_clip : p.scale_clip;
+        const double a = (q_a + k.esh) * k.invd;
+        const double ac = clipc(a, p.scale_clip);
+        const double E = exp(ac), Ei = fast_rcp(E);
+        const double sh = 0.5 * (E - Ei), ch = 0.5 * (E + Ei);
+        const double lch = log_cosh_from_exp(fabs(ac), fmin(E, Ei));
+        const double t = fma(k.s_, sh, xt[0]);
+        double logp, gdot;
+        bool need = line_point<MODEL, true>(p, st, t, cl, logp, gdot);
+        if (__any(need)) {
+            // the rare point behind the clip bound: the element-wise loop — for all four nodes of its half, as split_kl_group
+            // does (exact_points4 takes four points; here each lane passes its own four times)
+            need = ((__ballot(need) >> (threadIdx.x & 60)) & 0xFull) != 0;
+            if (need) {
+                const long long tb = tile_base(c, p.D, p.tw);
+                const Pts4 e = exact_points4<MODEL>(p.theta + tb, p.d_rho + tb, p.md.aux, p.D, p.tw, p.md.n, nn, t, t, t, t, cl);
+                logp = e.lp[0]; gdot = e.gd[0];
+            }
+        }
+        kl_node_terms<SUB>(q_w, a, sh, ch, lch, logp, gdot, k, cc);
+        f = grp_sum8(cc[0]); g[0] = grp_sum8(cc[1]); g[1] = grp_sum8(cc[2]); g[2] = grp_sum8(cc[3]);
+        g[3] = SUB ? 0.0 : grp_sum8(cc[4]);
+    }
+}
+#pragma clang fp contract(fast)
+
+template <int MODEL, int VARIANT>
+__global__ __launch_bounds__(64) void klhr_fitn_kernel(const KParams p) {
+    constexpr int N = VARIANT == VAR_GAUSS ? 2 : (VARIANT == VAR_SUB ? 3 : 4);
+    const int lane = threadIdx.x & 63, l8 = lane & 7;
+    const long long task = (long long)blockIdx.x * 8 + (lane >> 3);
+    if (task >= p.C) return;                    // (whole octets leave: the butterflies stay inside an octet)
+    const bool diag = (p.flags & FLAG_DIAG) != 0, lead = l8 == 0;
+    // this lane's quadrature node (a per-lane index into the kernel-argument tables would go through scratch)
+    double q_a = p.asx[0], q_x = p.xq[0], q_w = p.wq[0];
+#pragma unroll
+    for (int n = 1; n < 8; n++) if (l8 == n) { q_a = p.asx[n]; q_x = p.xq[n]; q_w = p.wq[n]; }
+    const LineStat st = load_stat(p, task);
+    const double nn = KLHR_FB(p, F_NN, task);
+    Opt o;
+    int npass = 0;
+    // ---- stage 1: minimize(logp_grad_rho, x0, BFGS, gtol = 1e-5) (klhr_sinh.py:183-190), every lane of the octet alike
+    {
+        double x0v[4] = {KLHR_FB(p, F_X0, task), 0, 0, 0};
+        if (diag && lead) p.d_diag[task * KLHR_NDIAG + KLHR_D_X0] = x0v[0];
+        opt_begin(o, 1, x0v, 1e-5);
+    }
+    bool live = true;
+    while (__any(live)) {
+        if (live) {
+            double f = 0, g[4] = {0, 0, 0, 0};
+            if (opt_cache_hit(o)) { f = o.lf; g[0] = o.lg[0]; }
+            else {
+                double lp, gd;
+                (void)line_point<MODEL, false>(p, st, o.xt[0], INFINITY, lp, gd);
+                f = -lp; g[0] = -gd;
+                opt_cache_store(o, f, g);
+                npass++;
+            }
+            opt_advance<false, 1>(o, f, g);
+            if (o.pc == PC_DONE || npass > KLHR_MAX_PASSES) live = false;
+        }
+    }
+    const bool capped1 = o.pc != PC_DONE;
+    const double mode = o.xk[0];
+    double s1 = o.H[0];
+    s1 = (s1 > 0 ? 1.0 : 0.0) * 0.5 * log(s1);
+    const int npass1 = npass, nfev1 = o.nfev;
+    if (lead) {
+        KLHR_FB(p, F_MODE, task) = mode; KLHR_FB(p, F_INIT1, task) = s1;
+        KLHR_FB(p, F_PASS, task) = (double)npass1; KLHR_FB(p, F_NFEV1, task) = (double)nfev1;
+        if (capped1) atomicOr(&p.status[task], 8);
+        if (diag) {
+            double *dd = p.d_diag + task * KLHR_NDIAG;
+            dd[KLHR_D_MODE] = o.xk[0]; dd[KLHR_D_HINV1] = o.H[0]; dd[KLHR_D_NFEV1] = o.nfev; dd[KLHR_D_NIT1] = o.k;
+            dd[KLHR_D_STATUS1] = o.status; dd[KLHR_D_FALLBACKS] = o.fallbacks;
+        }
+    }
+    const int fb1 = o.fallbacks;
+    // ---- stage 2: minimize(KL, init, BFGS, gtol = 1e-3) (klhr_sinh.py:191-201; klhr.py:134-139; sub_klhr_sinh.py:184-192)
+    {
+        const double init[4] = {mode, s1, VARIANT == VAR_GAUSS ? 0.0 : KLHR_FB(p, F_N2, task), VARIANT == VAR_SINH ? KLHR_FB(p, F_N3, task) : 0.0};
+        if (diag && lead) {
+            double *dd = p.d_diag + task * KLHR_NDIAG;
+            dd[KLHR_D_INIT0] = init[0]; dd[KLHR_D_INIT1] = init[1]; dd[KLHR_D_INIT2] = init[2]; dd[KLHR_D_INIT3] = init[3];
+        }
+        opt_begin(o, N, init, VARIANT == VAR_GAUSS ? 1e-5 : 1e-3);
+    }
+    npass = 0;
+    live = true;
+    while (__any(live)) {
+        if (live) {
+            double f = 0, g[4] = {0, 0, 0, 0};
+            if (opt_cache_hit(o)) { f = o.lf; g[0] = o.lg[0]; g[1] = o.lg[1]; g[2] = o.lg[2]; g[3] = o.lg[3]; }
+            else {
+                node_eval_kl<MODEL, VARIANT>(p, st, task, nn, o.xt, q_a, q_x, q_w, f, g);
+                opt_cache_store(o, f, g);
+                npass++;
+            }
+            opt_advance<false, N>(o, f, g);
+            if (o.pc == PC_DONE || npass > KLHR_MAX_PASSES) live = false;
+        }
+    }
+    if (l8 < 4) p.d_eta[task * 4 + l8] = l8 == 0 ? o.xk[0] : (l8 == 1 ? o.xk[1] : (l8 == 2 ? o.xk[2] : o.xk[3]));
+    if (lead) {
+        KLHR_FB(p, F_NFEV2, task) = (double)o.nfev;
+        if (o.pc != PC_DONE) atomicOr(&p.status[task], 8);
+        if (diag) {
+            double *dd = p.d_diag + task * KLHR_NDIAG;
+            dd[KLHR_D_NFEV2] = o.nfev; dd[KLHR_D_NIT2] = o.k; dd[KLHR_D_STATUS2] = o.status; dd[KLHR_D_FUN2] = o.old_fval;
+            dd[KLHR_D_FALLBACKS] = fb1 + o.fallbacks; dd[KLHR_D_PASSES] = npass1 + npass;
+        }
+    }
+}
+
 // KL / line probes of the C ABI (klhr_kl_eval, klhr_line_eval): one evaluation per chain at eta = d_eta
 template <int MODEL, int VARIANT>
 __global__ __launch_bounds__(64) void klhr_probe_kernel(const KParams p) {
-    const long long c = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
-    if (c >= p.C) return;
+    const long long c = (long long)blockIdx.x * p.fit_lanes + (threadIdx.x & 63);
+    if ((int)(threadIdx.x & 63) >= p.fit_lanes || c >= p.C) return;
     const LineStat st = load_stat(p, c);
     const double nn = KLHR_FB(p, F_NN, c);
     double eta[4], f = 0, g[4] = {0, 0, 0, 0};

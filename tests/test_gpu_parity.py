@@ -698,3 +698,28 @@ def test_asynchronous_chains_equal_synchronous_rounds(monkeypatch, kernel_mode):
         out.append((s.draws(0, 60), s.get("theta"), s.get("rng"), s.get("cov"), s.get("pca_v"), s.get("grad_evals"), s.get("acc"), s.get("counters")))
     for a, b in zip(out[0], out[1]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("name", ["funnel100", "illnormal100", "funnel10"])
+@pytest.mark.parametrize("variant,over", [(0, False), (0, True), (1, False), (2, False)])
+def test_node_parallel_fit_equals_lane_per_chain_fit(monkeypatch, kernel_mode, name, variant, over):
+    """Split pipeline: up to 32 768 chains both stages of fit() run in klhr_fitn_kernel (8 lanes per chain, one quadrature
+    node per lane, butterfly sums with the lane form's tree), above that in klhr_fit1_kernel / klhr_fit2_kernel (lane = chain).
+    Which one ran must not show in any bit of a chain's state — size independence (test_gpu_fullsize.py) rests on it.
+    The small clip bounds make the exact element-wise patch of the closed form (rare at the defaults) a common path."""
+    if kernel_mode != "split":
+        pytest.skip("the fit kernels of the split pipeline")
+    stem, data = model_spec(name)
+    C = 203
+    seeds = np.arange(C, dtype=np.uint64) + 4100
+    for clips in ({}, {"grad_clip": 3.0, "scale_clip": 3.0}):
+        out = []
+        for mode in ("0", "1"):
+            monkeypatch.setenv("KLHR_FITN", mode)
+            s = make_sampler(stem, data, C, warmup=100, variant=variant, overrelaxed=over, **clips)
+            s.seed(seeds)
+            s.step(70, record_diag=True)
+            assert ("fitn" in s.kernel_name()) == (mode == "1"), s.kernel_name()
+            out.append([s.get(f) for f in ("theta", "rng", "cov", "eigvecs", "pca_v", "grad_evals", "acc", "counters", "diag", "status")])
+        for a, b in zip(out[0], out[1]):
+            assert np.array_equal(a, b, equal_nan=True)
