@@ -475,8 +475,14 @@ __device__ __forceinline__ void for_chunks(int D, F f) {
     for (; i0 + CH <= D; i0 += CH) f(std::integral_constant<int, CH>(), i0);
     for (; i0 < D; ++i0) f(std::integral_constant<int, 1>(), i0);
 }
-constexpr int ST_CH = 8;          // passes over several arrays
-constexpr int ST_CH1 = 16;        // passes over one or two arrays
+#ifndef KLHR_ST_CH
+#define KLHR_ST_CH 8
+#endif
+#ifndef KLHR_ST_CH1
+#define KLHR_ST_CH1 16
+#endif
+constexpr int ST_CH = KLHR_ST_CH;          // passes over several arrays
+constexpr int ST_CH1 = KLHR_ST_CH1;        // passes over one or two arrays
 
 // Software-pipelined form: `load(buf, i0)` fills a register buffer with the chunk at i0, `compute(buf, i0)` consumes it.
 // The loads of chunk j+1 are issued before chunk j is computed (two buffers): a wavefront of this kernel has at most one
