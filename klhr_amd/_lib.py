@@ -216,7 +216,8 @@ class Sampler:
 
     def kernel_name(self):
         return {0: "klhr_iter_kernel", 1: "klhr_lane_kernel", 2: "klhr_stream_kernel+klhr_fit1_kernel+klhr_fit2_kernel",
-                3: "klhr_stream_kernel+klhr_fitn_kernel"}[self._L.klhr_kernel_variant(self._h)]
+                3: "klhr_stream_kernel+klhr_fitn_kernel",
+                4: "klhr_stream_kernel+klhr_fit1_kernel+klhr_fit2_kernel+klhr_fit2r_kernel"}[self._L.klhr_kernel_variant(self._h)]
 
     def draws(self, first=0, n=None, total=None):
         n = int(n)
@@ -236,7 +237,8 @@ class Sampler:
 
     def kernel_names(self):
         return {0: ["klhr_iter_kernel"], 1: ["klhr_lane_kernel"], 2: ["klhr_stream_kernel", "klhr_fit1_kernel", "klhr_fit2_kernel"],
-                3: ["klhr_stream_kernel", "(none)", "klhr_fitn_kernel"]}[self._L.klhr_kernel_variant(self._h)]
+                3: ["klhr_stream_kernel", "(none)", "klhr_fitn_kernel"],
+                4: ["klhr_stream_kernel", "klhr_fit1_kernel", "klhr_fit2_kernel+klhr_fit2r_kernel"]}[self._L.klhr_kernel_variant(self._h)]
 
     def timing(self):
         ms = C.c_double()

@@ -100,6 +100,7 @@ struct klhr_sampler {
     int comm_rank = 0, comm_world = 0;
     bool async_ok = false;       // klhr_step lets chains progress asynchronously (split pipeline)
     bool fitn = false;           // split pipeline: both fit stages in the node-parallel kernel (few chains: klhr_fitn_kernel)
+    bool resume = false;         // split pipeline, many chains: long KL fits are handed to the node-parallel resume kernel
     unsigned int *h_pend = nullptr;      // pinned host copy of the groups' pending-chain counters
     bool profile = false;
     std::vector<hipEvent_t> pev;
@@ -209,7 +210,7 @@ extern "C" int klhr_device_count(void) {
 extern "C" const char *klhr_last_error(const klhr_sampler *s) { return s ? s->err.c_str() : g_create_err.c_str(); }
 extern "C" int klhr_dim(const klhr_sampler *s) { return s ? s->D : KLHR_ERR_ARG; }
 extern "C" int klhr_chains(const klhr_sampler *s) { return s ? s->C : KLHR_ERR_ARG; }
-extern "C" int klhr_kernel_variant(const klhr_sampler *s) { return s ? (s->split ? (s->fitn ? 3 : 2) : (s->use_lane ? 1 : 0)) : KLHR_ERR_ARG; }
+extern "C" int klhr_kernel_variant(const klhr_sampler *s) { return s ? (s->split ? (s->fitn ? 3 : (s->resume ? 4 : 2)) : (s->use_lane ? 1 : 0)) : KLHR_ERR_ARG; }
 
 // ---- host <-> device copies of [C][W] state arrays: the host side is always chain-major (the NumPy layout); the device
 // side is tiled [tile][w][64 lanes] for handles of the split pipeline
@@ -402,6 +403,18 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
         // 159, 32 768: 118 / 171, 65 536: 204 / 183, funnel-100 x 131 072: 952 / 676 — from 65 536 chains on lane = chain has the throughput
         s->fitn = C <= 32768;
         if (const char *e = getenv("KLHR_FITN")) s->fitn = atoi(e) != 0;
+        // many chains (opt-in, KLHR_FIT_RESUME=1, budget KLHR_FIT_RESUME_BUDGET): the lane = chain KL fit stops at a pass budget and
+        // hands the unfinished fits (the thin long tail: funnel-100 median 13 passes, 1 % >= 28, rare 60-75) to the node-parallel
+        // resume kernel.  Measured on funnel-100 x 131 072: KL fit 634 us -> 266 + 221 us (budget 14) with one chain group, but
+        // 918 vs 920 us per iteration with the default four groups — the other groups' kernels already fill the SIMDs that a
+        // fit launch's tail leaves idle, and the tail's own latency (60 passes x 3 us) stays.  Off by default.
+        TRY(dalloc(s, &k.resume_list, C)); TRY(dalloc(s, &k.resume_count, 16));
+        TRY(hip_try(hipMemsetAsync(k.resume_count, 0, 16 * sizeof(unsigned int), s->stream), "hipMemsetAsync"));
+        s->resume = false;
+        if (const char *e = getenv("KLHR_FIT_RESUME")) s->resume = atoi(e) != 0 && !s->fitn;
+        k.resume_budget = 16;
+        if (const char *e = getenv("KLHR_FIT_RESUME_BUDGET")) { const int v = atoi(e); if (v >= 1) k.resume_budget = v; }
+        if (!s->resume) k.resume_budget = 0;
         if (const char *e = getenv("KLHR_FIT_BUDGET1")) { const int v = atoi(e); if (v >= 1) k.budget1 = v; }
         if (const char *e = getenv("KLHR_FIT_BUDGET2")) { const int v = atoi(e); if (v >= 1) k.budget2 = v; }
         // Chain groups of klhr_step: the streaming kernel is bound by memory, the fit kernels by the fp64 ALUs; with the chains
@@ -529,6 +542,7 @@ static bool group_view(const klhr_sampler *s, const KParams &kp, int g, int G, K
     out.fitbuf += c0;
     if (out.draws) out.draws += c0 * D;
     out.phase += c0; out.togo += c0; out.optbuf = reinterpret_cast<Opt *>(out.optbuf) + c0; out.pend += g;
+    out.resume_list += c0; out.resume_count += g;
     return true;
 }
 
@@ -640,6 +654,7 @@ static int run_phases(klhr_sampler *s, int phases, int64_t n_iters, int record_d
                     if (!s->fitn) launch_split(s, kp, 1, 0, 0, st);
                     if (mark((int)it * 4 + 2)) return KLHR_ERR_HIP;
                     launch_split(s, kp, s->fitn ? 4 : 2, 0, 0, st);
+                    if (!s->fitn && kp.resume_budget) launch_split(s, kp, 5, 0, 0, st);
                     if (mark((int)it * 4 + 3)) return KLHR_ERR_HIP;
                 }
                 if (it < n_iters && (phases & (PH_KL | PH_LINE))) {

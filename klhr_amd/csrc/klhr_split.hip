@@ -30,6 +30,10 @@ static void launch_split_model(const KParams &kp0, int what, bool overrelaxed, i
         hipLaunchKernelGGL((klhr_fit1_kernel<MODEL>), dim3(fitgrid), block, 0, stream, kp);
     } else if (what == 2) {
         hipLaunchKernelGGL((klhr_fit2_kernel<MODEL, V>), dim3(fitgrid), block, 0, stream, kp);
+    } else if (what == 5) {
+        unsigned grid = (unsigned)((kp.C + 7) / 8);
+        if (grid > 2048) grid = 2048;           // (grid-stride over the list: the handed-over fits are a few per cent of the chains)
+        hipLaunchKernelGGL((klhr_fit2r_kernel<MODEL, V>), dim3(grid), block, 0, stream, kp);
     } else if (what == 4) {
         hipLaunchKernelGGL((klhr_fitn_kernel<MODEL, V>), dim3((unsigned)((kp.C + 7) / 8)), block, 0, stream, kp);
     } else if (what == 3) {
@@ -47,7 +51,8 @@ static void launch_split_model(const KParams &kp0, int what, bool overrelaxed, i
     }
 }
 
-// what: 0 streaming kernel (do_tail / do_head), 1 mode search, 2 KL fit, 3 KL / line probe, 4 both fit stages node-parallel
+// what: 0 streaming kernel (do_tail / do_head), 1 mode search, 2 KL fit, 3 KL / line probe, 4 both fit stages node-parallel,
+// 5 node-parallel resume of the KL fits klhr_fit2_kernel handed over
 void KLHR_CAT2(launch_split_v, KLHR_VARIANT)(const KParams &kp, int model_id, int what, bool overrelaxed, int do_tail, int do_head, hipStream_t stream) {
     switch (model_id) {
     case KLHR_MODEL_FUNNEL: launch_split_model<MODEL_FUNNEL>(kp, what, overrelaxed, do_tail, do_head, stream); break;

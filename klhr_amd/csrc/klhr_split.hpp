@@ -182,6 +182,7 @@ __device__ __forceinline__ void opt_restore(const KParams &p, long long c, Opt &
 template <int MODEL>
 __global__ __launch_bounds__(64) void klhr_fit1_kernel(const KParams p) {
     const int lane = threadIdx.x & 63;
+    if (p.resume_budget && blockIdx.x == 0 && threadIdx.x == 0) *p.resume_count = 0;      // (the KL fit of this round fills the list)
     const long long task = (long long)blockIdx.x * p.fit_lanes + lane;
     if (lane >= p.fit_lanes || task >= p.C) return;
     const bool diag = (p.flags & FLAG_DIAG) != 0;
@@ -264,7 +265,8 @@ __global__ __launch_bounds__(64) void klhr_fit2_kernel(const KParams p) {
         }
         opt_begin(o, N, init, VARIANT == VAR_GAUSS ? 1e-5 : 1e-3);
     }
-    const int budget = p.async_mode ? p.budget2 : KLHR_MAX_PASSES;
+    const bool hand_over = !p.async_mode && p.resume_budget > 0;
+    const int budget = p.async_mode ? p.budget2 : (hand_over ? p.resume_budget : KLHR_MAX_PASSES);
     bool live = true;
     int ltrips = 0;
     while (__any(live)) {
@@ -293,6 +295,10 @@ __global__ __launch_bounds__(64) void klhr_fit2_kernel(const KParams p) {
                 live = false;
             } else if (ltrips >= budget) {
                 opt_save(p, task, o, npass);
+                if (hand_over) {          // (a few per cent of the chains: plain atomics)
+                    KLHR_FB(p, F_PASS1, task) = (double)npass1;
+                    p.resume_list[atomicAdd(p.resume_count, 1u)] = (int)task;
+                }
                 ph = PHS_FIT2_RESUME;
                 live = false;
             }
@@ -437,6 +443,58 @@ __global__ __launch_bounds__(64) void klhr_fitn_kernel(const KParams p) {
             double *dd = p.d_diag + task * KLHR_NDIAG;
             dd[KLHR_D_NFEV2] = o.nfev; dd[KLHR_D_NIT2] = o.k; dd[KLHR_D_STATUS2] = o.status; dd[KLHR_D_FUN2] = o.old_fval;
             dd[KLHR_D_FALLBACKS] = fb1 + o.fallbacks; dd[KLHR_D_PASSES] = npass1 + npass;
+        }
+    }
+}
+
+// The KL fits that klhr_fit2_kernel handed over (KParams::resume_budget): node-parallel from the saved optimiser state on.
+// The distribution of a fit's passes is narrow with a thin long tail (funnel-100: median 13, 90 % <= 14, 1 % >= 28, rare 60-75):
+// lane = chain, one such chain holds its 63 neighbours' lanes idle and the launch lasts as long as the slowest chain; here
+// the tail runs 8 lanes per chain (a third of the latency per pass) on its own few wavefronts.  Same arithmetic per pass as
+// klhr_fit2_kernel: where a fit is finished shows in no bit of the result.
+template <int MODEL, int VARIANT>
+__global__ __launch_bounds__(64) void klhr_fit2r_kernel(const KParams p) {
+    constexpr int N = VARIANT == VAR_GAUSS ? 2 : (VARIANT == VAR_SUB ? 3 : 4);
+    const int lane = threadIdx.x & 63, l8 = lane & 7;
+    const bool diag = (p.flags & FLAG_DIAG) != 0, lead = l8 == 0;
+    const unsigned int count = *p.resume_count;
+    double q_a = p.asx[0], q_x = p.xq[0], q_w = p.wq[0];
+#pragma unroll
+    for (int n = 1; n < 8; n++) if (l8 == n) { q_a = p.asx[n]; q_x = p.xq[n]; q_w = p.wq[n]; }
+    for (unsigned int first = blockIdx.x * 8u; first < count; first += gridDim.x * 8u) {       // (wave-uniform bounds)
+        const unsigned int item = first + (unsigned int)(lane >> 3);
+        if (item < count) {                     // (whole octets: the butterflies stay inside an octet)
+            const long long task = p.resume_list[item];
+            const LineStat st = load_stat(p, task);
+            const double nn = KLHR_FB(p, F_NN, task);
+            Opt o;
+            opt_restore(p, task, o);
+            int npass = (int)KLHR_FB(p, F_PASS, task);
+            const int npass1 = (int)KLHR_FB(p, F_PASS1, task);
+            bool live = true;
+            while (__any(live)) {
+                if (live) {
+                    double f = 0, g[4] = {0, 0, 0, 0};
+                    if (opt_cache_hit(o)) { f = o.lf; g[0] = o.lg[0]; g[1] = o.lg[1]; g[2] = o.lg[2]; g[3] = o.lg[3]; }
+                    else {
+                        node_eval_kl<MODEL, VARIANT>(p, st, task, nn, o.xt, q_a, q_x, q_w, f, g);
+                        opt_cache_store(o, f, g);
+                        npass++;
+                    }
+                    opt_advance<false, N>(o, f, g);
+                    if (o.pc == PC_DONE || npass > KLHR_MAX_PASSES) live = false;
+                }
+            }
+            if (l8 < 4) p.d_eta[task * 4 + l8] = l8 == 0 ? o.xk[0] : (l8 == 1 ? o.xk[1] : (l8 == 2 ? o.xk[2] : o.xk[3]));
+            if (lead) {
+                KLHR_FB(p, F_NFEV2, task) = (double)o.nfev;
+                if (o.pc != PC_DONE) atomicOr(&p.status[task], 8);
+                if (diag) {
+                    double *dd = p.d_diag + task * KLHR_NDIAG;
+                    dd[KLHR_D_NFEV2] = o.nfev; dd[KLHR_D_NIT2] = o.k; dd[KLHR_D_STATUS2] = o.status; dd[KLHR_D_FUN2] = o.old_fval;
+                    dd[KLHR_D_FALLBACKS] += o.fallbacks; dd[KLHR_D_PASSES] = npass1 + npass;
+                }
+            }
         }
     }
 }

@@ -723,3 +723,28 @@ def test_node_parallel_fit_equals_lane_per_chain_fit(monkeypatch, kernel_mode, n
             out.append([s.get(f) for f in ("theta", "rng", "cov", "eigvecs", "pca_v", "grad_evals", "acc", "counters", "diag", "status")])
         for a, b in zip(out[0], out[1]):
             assert np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.parametrize("variant,over", [(0, False), (0, True), (1, False), (2, False)])
+def test_handed_over_fits_equal_fits_finished_in_place(monkeypatch, kernel_mode, variant, over):
+    """KLHR_FIT_RESUME=1 (split pipeline, lane = chain fit kernels): the KL fit stops at a pass budget and the unfinished fits
+    are finished by the node-parallel resume kernel from the saved optimiser state.  A budget of 3 hands over nearly every
+    fit, 14 the tail only; neither may show in any bit of a chain's state."""
+    if kernel_mode != "split":
+        pytest.skip("the fit kernels of the split pipeline")
+    stem, data = model_spec("funnel100")
+    C = 203
+    seeds = np.arange(C, dtype=np.uint64) + 7300
+    monkeypatch.setenv("KLHR_FITN", "0")
+    out = []
+    for resume, budget in (("0", "1"), ("1", "3"), ("1", "14")):
+        monkeypatch.setenv("KLHR_FIT_RESUME", resume)
+        monkeypatch.setenv("KLHR_FIT_RESUME_BUDGET", budget)
+        s = make_sampler(stem, data, C, warmup=100, variant=variant, overrelaxed=over)
+        s.seed(seeds)
+        s.step(70, record_diag=True)
+        assert ("fit2r" in s.kernel_name()) == (resume == "1"), s.kernel_name()
+        out.append([s.get(f) for f in ("theta", "rng", "cov", "eigvecs", "pca_v", "grad_evals", "acc", "counters", "diag", "status")])
+    for o in out[1:]:
+        for a, b in zip(out[0], o):
+            assert np.array_equal(a, b, equal_nan=True)
