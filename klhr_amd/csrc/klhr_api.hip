@@ -433,6 +433,12 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
         size_t nw = zb ? cap / zb : 4;
         k.stream_waves = (int)(nw < 1 ? 1 : (nw > 4 ? 4 : nw));
         if (const char *e = getenv("KLHR_STREAM_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 4) k.stream_waves = v; }
+        // two wavefronts per tile (tail | head) in the streaming kernel, for launches with a tail and a head on 16-chain tiles
+        // (klhr_split.hip) while both wavefronts of every tile are resident at once: up to 16 384 chains (1 024 tiles, 2 048
+        // wavefronts at two per SIMD).  ill-normal-100: 4 096 chains 213 -> 145 us per iteration, 8 192: 233 -> 152, 16 384: 224 -> 177
+        // (159 with two chain groups), 32 768: 296 -> 311 (second round of wavefronts: off).
+        k.stream_pair = s->C <= 16384;
+        if (const char *e = getenv("KLHR_STREAM_PAIR")) k.stream_pair = atoi(e) != 0;
         k.fit_lanes = 0;           // 0: chosen per launch from the chain count of the launch (klhr_split.hip)
         if (const char *e = getenv("KLHR_FIT_LANES")) { const int v = atoi(e); if (v == 8 || v == 16 || v == 32 || v == 64) k.fit_lanes = v; }
     }

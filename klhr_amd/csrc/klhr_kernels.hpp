@@ -70,6 +70,7 @@ struct KParams {
     long long draw_stride;       // doubles between two recorded iterations in `draws` (handle's chains x D)
     double *fitbuf;              // per-chain fit records, SoA [F_NFIELDS][fstride]
     int fit_lanes;               // fit / probe kernels: chains per wavefront (64, 32, 16 or 8; the other lanes leave at once)
+    int stream_pair;             // streaming kernel: two wavefronts per tile (tail | head), narrow tiles in the synchronous rounds (klhr_split.hpp)
     int stream_waves;            // streaming kernel: wavefronts (tiles) per workgroup, sharing one LDS copy of the ziggurat tables
     // asynchronous chains (klhr_step on the split pipeline): every chain advances through head -> mode search -> KL fit ->
     // tail at its own pace.  A fit launch gives every chain at most `budget` objective passes; a chain that is not done keeps

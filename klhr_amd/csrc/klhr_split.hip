@@ -23,7 +23,11 @@ static void launch_split_model(const KParams &kp0, int what, bool overrelaxed, i
     if (kp.fit_lanes <= 0) kp.fit_lanes = 64;
     const unsigned tiles = (unsigned)((kp.C + kp.fit_lanes - 1) / kp.fit_lanes);
     const unsigned stiles = (unsigned)(kp.Cpad / kp.tw);          // streaming kernel: one wavefront per tile of tw chains,
-    const unsigned sgroups = (stiles + kp.stream_waves - 1) / kp.stream_waves;      // stream_waves tiles per workgroup
+    // pair mode (two wavefronts per tile, klhr_split.hpp): a launch that runs a tail AND a head on narrow tiles, synchronous rounds
+    if (kp.stream_pair && kp.tw == 16 && do_tail && do_head && !kp.async_mode && kp.stream_waves >= 2) kp.stream_waves &= ~1;
+    else kp.stream_pair = 0;
+    const unsigned tiles_wg = kp.stream_pair ? kp.stream_waves / 2 : kp.stream_waves;
+    const unsigned sgroups = (stiles + tiles_wg - 1) / tiles_wg;                    // tiles_wg tiles per workgroup
     const dim3 block(64), sblock(64 * kp.stream_waves);
     const unsigned fitgrid = tiles;
     if (what == 1) {
@@ -39,14 +43,14 @@ static void launch_split_model(const KParams &kp0, int what, bool overrelaxed, i
     } else if (what == 3) {
         hipLaunchKernelGGL((klhr_probe_kernel<MODEL, V>), dim3(tiles), block, 0, stream, kp);
     } else {
-        const size_t lds = ((size_t)kp.stream_waves * kp.D * kp.tw + KLHR_ZTAB_DOUBLES) * sizeof(double);
-#define KLHR_LAUNCH_STREAM(O, TW)                                                                                                      \
+        const size_t lds = ((size_t)kp.stream_waves * kp.D * kp.tw + KLHR_ZTAB_DOUBLES + (kp.stream_pair ? (size_t)tiles_wg * 4 * kp.tw + 1 : 0)) * sizeof(double);
+#define KLHR_LAUNCH_STREAM(KERNEL, O)                                                                                                  \
     do {                                                                                                                               \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)klhr_stream_kernel<MODEL, O, V, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((klhr_stream_kernel<MODEL, O, V, TW>), dim3(sgroups), sblock, lds, stream, kp, do_tail, do_head);                \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)KERNEL<MODEL, O, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((KERNEL<MODEL, O, V>), dim3(sgroups), sblock, lds, stream, kp, do_tail, do_head);                            \
     } while (0)
-        if (kp.tw == 16) { if (overrelaxed) KLHR_LAUNCH_STREAM(true, 16); else KLHR_LAUNCH_STREAM(false, 16); }
-        else { if (overrelaxed) KLHR_LAUNCH_STREAM(true, 64); else KLHR_LAUNCH_STREAM(false, 64); }
+        if (kp.tw == 16) { if (overrelaxed) KLHR_LAUNCH_STREAM(klhr_stream16_kernel, true); else KLHR_LAUNCH_STREAM(klhr_stream16_kernel, false); }
+        else { if (overrelaxed) KLHR_LAUNCH_STREAM(klhr_stream_kernel, true); else KLHR_LAUNCH_STREAM(klhr_stream_kernel, false); }
 #undef KLHR_LAUNCH_STREAM
     }
 }

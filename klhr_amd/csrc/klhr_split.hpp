@@ -539,8 +539,10 @@ __device__ __forceinline__ void for_chunks(int D, F f) {
 #ifndef KLHR_ST_CH1
 #define KLHR_ST_CH1 16
 #endif
-constexpr int ST_CH = KLHR_ST_CH;          // passes over several arrays
-constexpr int ST_CH1 = KLHR_ST_CH1;        // passes over one or two arrays
+// (inside functions templated on the tile width W.  16-chain tiles: half the chunk — measured the same speed, and the
+//  streaming kernel then fits 256 registers, i.e. two wavefronts per SIMD, which its pair mode needs)
+#define ST_CH (W == 16 ? KLHR_ST_CH / 2 : KLHR_ST_CH)          // passes over several arrays
+#define ST_CH1 (W == 16 ? KLHR_ST_CH1 / 2 : KLHR_ST_CH1)       // passes over one or two arrays
 
 // Software-pipelined form: `load(buf, i0)` fills a register buffer with the chunk at i0, `compute(buf, i0)` consumes it.
 // The loads of chunk j+1 are issued before chunk j is computed (two buffers): a wavefront of this kernel has at most one
@@ -712,20 +714,38 @@ __device__ __forceinline__ void line_accumulate(const KParams &p, int i, double 
 // A workgroup is p.stream_waves wavefronts (1-4), each with its own tile and its own LDS column block; the workgroup shares
 // one LDS copy of the ziggurat's WI / KI tables for the direction draw (4 KB; D = 100 x 64 lanes: three 51 200 B column
 // blocks + the tables = 157.7 KB, one workgroup per CU).
+// PAIR mode (p.stream_pair: narrow tiles, i.e. few chains, in the synchronous rounds): TWO wavefronts per tile.  With few chains
+// a launch lasts as long as one wavefront's walk through its phases, and half of them do not depend on the other half: the
+// next direction's normals need only the RNG state after the MH draws, the direction pass only theta' (and, at a window
+// closure, the new mean / cov / eigenvectors).  Wavefront A runs the tail (MH scalars | T1 | CCIPCA or closure), wavefront B
+// the head (normals | direction + line sums), each with its own LDS column, meeting at three workgroup barriers:
+//   b1 after the MH scalars (A hands the RNG state over in LDS), b2 after T1 (theta' is in HBM), b3 after the tail —
+// B's direction pass goes before b3 unless a chain of the workgroup closes a window.  Every chain's arithmetic is the
+// single-wavefront form's, operation for operation.
 template <int MODEL, bool OVERRELAX, int VARIANT, int W>
-__global__ __launch_bounds__(256) void klhr_stream_kernel(const KParams p, const int do_tail, const int do_head) {
+__device__ __forceinline__ void stream_body(const KParams &p, const int do_tail, const int do_head) {
     extern __shared__ double lds[];            // [waves][D][W] column scratch (normals, then theta - mean), then the ziggurat tables
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const long long tile = (long long)blockIdx.x * p.stream_waves + wv;
+    const bool pair = p.stream_pair != 0;
+    const int role = pair ? (wv & 1) : 2;                       // 0: the tile's tail, 1: the tile's head, 2: both (one wavefront per tile)
+    const int tslot = pair ? wv >> 1 : wv;                      // the workgroup's tile this wavefront works on
+    const int tiles_wg = pair ? p.stream_waves >> 1 : p.stream_waves;
+    const long long tile = (long long)blockIdx.x * tiles_wg + tslot;
     const long long c = tile * W + lane;
     const int D = p.D, nc = p.ncol, K = p.J;
-    double *Z = lds + (size_t)wv * D * W + lane;
+    double *Z = lds + (size_t)tslot * (pair ? 2 : 1) * D * W + lane;       // tail: u = theta' - mean
+    double *Zn = pair ? Z + (size_t)D * W : Z;                              // head: the normals (pair mode: a column of its own)
     double *zwi = lds + (size_t)p.stream_waves * D * W;
     uint64_t *zki = reinterpret_cast<uint64_t *>(zwi + 256);
-    if (do_head && (p.phases & PH_DIR)) {
+    // pair mode: per tile 4 x W words for the RNG hand-over, then one word per workgroup: a chain closes a window in this launch
+    unsigned long long *hand = reinterpret_cast<unsigned long long *>(zwi + 512) + (size_t)tslot * 4 * W + lane;
+    int *closing = reinterpret_cast<int *>(zwi + 512 + (size_t)tiles_wg * 4 * W);
+    if ((do_head && (p.phases & PH_DIR)) || pair) {
         for (int i = threadIdx.x; i < 256; i += blockDim.x) { zwi[i] = KLHR_ZIG_WI[i]; zki[i] = KLHR_ZIG_KI[i]; }
+        if (pair && threadIdx.x == 0) *closing = 0;
         __syncthreads();
     }
+    // (a wavefront whose tile lies beyond the last chain ends here; s_barrier waits for the surviving wavefronts only)
     if (lane >= W || c >= p.C) return;
     // async mode: a chain takes part in this launch with the tail of its finished fit (PHS_TAIL) and / or the head of its
     // next iteration (PHS_HEAD, while it has draws to go); chains in the middle of a fit sit the launch out
@@ -761,11 +781,13 @@ __global__ __launch_bounds__(256) void klhr_stream_kernel(const KParams p, const
 
     KLHR_STAMP(st_state);
     // =================================================================== tail of iteration k (klhr_sinh.py:266-287)
-    if (run_tail) {
+    const bool tail_here = run_tail && role != 1, head_here = run_head && role != 0;
+    const bool mh = (p.phases & PH_MH) != 0, adapt = (p.phases & PH_ADAPT) != 0;
+    double zp = 0.0, ad = 0.0, na = 1.0, nn = 1.0, w = 1.0;
+    bool closed = false, upd = false, closing_any = false;
+    if (tail_here) {
         // grad_evals += nfev1 + 8 nfev2 of the fit that preceded this tail (klhr_sinh.py:188,200)
         if (p.phases & PH_FIT) p.grad_evals[c] += (long long)KLHR_FB(p, F_NFEV1, c) + 8 * (long long)KLHR_FB(p, F_NFEV2, c);
-        const bool mh = (p.phases & PH_MH) != 0, adapt = (p.phases & PH_ADAPT) != 0;
-        double zp = 0.0, ad = 0.0, na = 1.0, nn = 1.0;
         if (mh) {
             const LineStat st = load_stat(p, c);
             nn = KLHR_FB(p, F_NN, c);
@@ -798,20 +820,33 @@ __global__ __launch_bounds__(256) void klhr_stream_kernel(const KParams p, const
             if (diag) { double *dd = p.d_diag + c * KLHR_NDIAG; dd[KLHR_D_ZP] = zp; dd[KLHR_D_R] = r; dd[KLHR_D_LOGU] = logu; dd[KLHR_D_ACCEPT] = a; }
         }
         KLHR_STAMP(st_mh);
-        bool closed = false;
         if (adapt && !(p.warmup < p.windowsize) && p.nclos > 0) {
             closed = draw == p.closures[cidx];
             if (closed && cidx < p.nclos - 1) cidx++;
         }
-        const bool upd = adapt && !closed;
+        upd = adapt && !closed;
         if (upd) omN += 1;
-        const double w = 1.0 / (double)omN;
+        w = 1.0 / (double)omN;
+    }
+    if (pair) {          // b1: the RNG state after the MH draws goes to the head's wavefront
+        if (role == 0) {
+            hand[0] = rng.sh; hand[W] = rng.sl; hand[2 * W] = rng.ih; hand[3 * W] = rng.il;
+            if (closed) *closing = 1;
+        }
+        __syncthreads();
+        if (role == 1) {
+            rng.sh = hand[0]; rng.sl = hand[W]; rng.ih = hand[2 * W]; rng.il = hand[3 * W];
+            closing_any = *closing != 0;
+        }
+    }
+    double u_choice = 0.0, ssq = 0.0;
+    if (tail_here) {
         // recorded draws: slot = the chain's own draw index within this call (chains may be rounds apart in async mode)
         long long slot = (long long)p.draw_slot;
         if (p.async_mode) { const int tg = p.togo[c]; slot = (long long)p.n_iters - tg; p.togo[c] = tg - 1; }
         double *out = p.draws ? p.draws + slot * p.draw_stride + c * D : nullptr;
         // ---- pass T1: theta' = a (theta + zp rho) + (1 - a) theta; OnlineMoments(theta'); Z = theta' - mean
-        double d2 = 0.0, ssq = 0.0;
+        double d2 = 0.0;
         bool fin = true;
         double *const om_m = p.om_m + tb, *const om_v = p.om_v + tb;
         const double *const mean = p.mean + tb;
@@ -853,6 +888,24 @@ __global__ __launch_bounds__(256) void klhr_stream_kernel(const KParams p, const
         if (mh && VARIANT == VAR_GAUSS) moved_f = (sqrt(d2) > 0.0) ? 1.0 : 0.0;
         if (!fin) atomicOr(&p.status[c], 2);
         KLHR_STAMP(st_t1);
+    }
+    // the D normals of the next direction (klhr_sinh.py:207-212; eigen_method_one: rng.choice() consumes one uniform BEFORE them).
+    // (64 lanes: a lane in the ziggurat's slow branch parks while the others go on; 16 lanes: the slow branch is rare
+    //  enough per wavefront-draw — 18 % — that the plain loop is faster, measured 64 k vs 89 k cycles per 100 normals)
+    auto draw_normals = [&]() {
+        u_choice = (p.flags & FLAG_EIGEN_ONE) ? pcg_next_double(rng) : 0.0;
+        if constexpr (W >= 32) rng_std_normal_column(rng, Zn, W, D, zwi, zki);
+        else { for (int k = 0; k < D; k++) Zn[k * W] = rng_std_normal_tab(rng, zwi, zki); }
+    };
+    if (pair) {          // the head's wavefront draws the normals while the tail's runs T1; b2: theta' is in HBM
+        if (role == 1 && run_head && (p.phases & PH_DIR)) draw_normals();
+        __syncthreads();
+    }
+    // pass 0: the rest of the tail; the head follows in pass 1 — in pair mode its wavefront runs it in pass 0 already, beside
+    // the other wavefront's CCIPCA, unless a chain of the workgroup closes a window (mean / cov / eigenvectors / ranks change)
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+    if (pass == 0 && tail_here) {
         if (closed) {
             split_close_window<W>(p, c, tb, tbe, tbv, omN, Z);
             omN = 0;
@@ -899,17 +952,12 @@ __global__ __launch_bounds__(256) void klhr_stream_kernel(const KParams p, const
     }
 
     // =================================================================== head of iteration k+1 (klhr_sinh.py:264-265)
-    if (run_head) {
+    if (head_here && pass == (role == 2 || closing_any ? 1 : 0)) {
         double nn = 1.0;
         LineStat st = {0, 0, 0, 0, 0, 0, 0};
         double Bs = 0, Cs = 0, m1 = 0;       // direction sums, still on the unnormalised r
         if (p.phases & PH_DIR) {
-            // eigen_method_one: rng.choice() consumes one uniform BEFORE the D normals (klhr_sinh.py:207,212)
-            const double u_choice = (p.flags & FLAG_EIGEN_ONE) ? pcg_next_double(rng) : 0.0;
-            // (64 lanes: a lane in the ziggurat's slow branch parks while the others go on; 16 lanes: the slow branch is rare
-            //  enough per wavefront-draw — 18 % — that the plain loop is faster, measured 64 k vs 89 k cycles per 100 normals)
-            if constexpr (W >= 32) rng_std_normal_column(rng, Z, W, D, zwi, zki);
-            else { for (int k = 0; k < D; k++) Z[k * W] = rng_std_normal_tab(rng, zwi, zki); }
+            if (role == 2) draw_normals();
             KLHR_STAMP(st_norm);
             const double *ev = p.eigvals + c * nc;
             double pj[4] = {0, 0, 0, 0};
@@ -959,7 +1007,7 @@ __global__ __launch_bounds__(256) void klhr_stream_kernel(const KParams p, const
                             if (nc > 2) m += wj[2] * b.e2[k];
                             if (nc > 3) m += wj[3] * evec[i * es + 3 * W];
                         }
-                        const double r = m + sqrt(b.cv[k]) * Z[b.rk[k] * W];
+                        const double r = m + sqrt(b.cv[k]) * Zn[b.rk[k] * W];
                         n2 += (r + p.tol) * (r + p.tol);
                         rho[i * W] = r;
                         line_accumulate<MODEL>(p, i, b.th[k], r, st, Bs, Cs, m1);
@@ -1004,13 +1052,17 @@ __global__ __launch_bounds__(256) void klhr_stream_kernel(const KParams p, const
         }
         KLHR_STAMP(st_dir);
     }
+    if (pass == 0 && pair) __syncthreads();          // b3: the tail is complete
+    }
 
-    // ---- store the per-chain scalars
+    // ---- store the per-chain scalars (pair mode: the RNG state by the head's wavefront, the rest by the tail's)
     if (p.async_mode) p.phase[c] = run_head ? PHS_FIT1 : PHS_HEAD;
-    p.rng[c * 4 + 0] = rng.sh; p.rng[c * 4 + 1] = rng.sl; p.rng[c * 4 + 2] = rng.ih; p.rng[c * 4 + 3] = rng.il;
-    p.counters[c * 4 + 0] = draw; p.counters[c * 4 + 1] = omN; p.counters[c * 4 + 2] = pcan; p.counters[c * 4 + 3] = cidx;
-    p.acc[c] = acc;
-    if (VARIANT == VAR_GAUSS) { p.kstate[c * 4 + 0] = sm_x; p.kstate[c * 4 + 1] = sm_cnt; p.kstate[c * 4 + 2] = (double)Kc; p.kstate[c * 4 + 3] = moved_f; }
+    if (role != 0) { p.rng[c * 4 + 0] = rng.sh; p.rng[c * 4 + 1] = rng.sl; p.rng[c * 4 + 2] = rng.ih; p.rng[c * 4 + 3] = rng.il; }
+    if (role != 1) {
+        p.counters[c * 4 + 0] = draw; p.counters[c * 4 + 1] = omN; p.counters[c * 4 + 2] = pcan; p.counters[c * 4 + 3] = cidx;
+        p.acc[c] = acc;
+        if (VARIANT == VAR_GAUSS) { p.kstate[c * 4 + 0] = sm_x; p.kstate[c * 4 + 1] = sm_cnt; p.kstate[c * 4 + 2] = (double)Kc; p.kstate[c * 4 + 3] = moved_f; }
+    }
 #ifdef KLHR_STAMPS
     KLHR_STAMP(st_fin);
     if (lane == 0) {      // diagnostic build: cycle totals of this launch's phases, accumulated in the tile's first diag row
@@ -1019,6 +1071,16 @@ __global__ __launch_bounds__(256) void klhr_stream_kernel(const KParams p, const
         ds[5] += (double)st_dir; ds[6] += (double)st_fin; ds[7] += 1.0;
     }
 #endif
+}
+// the two entry points: 64-chain tiles (one wavefront per SIMD: 452 registers, the LDS column bounds the occupancy anyway) and
+// 16-chain tiles (two wavefronts per SIMD)
+template <int MODEL, bool OVERRELAX, int VARIANT>
+__global__ __launch_bounds__(256) void klhr_stream_kernel(const KParams p, const int do_tail, const int do_head) {
+    stream_body<MODEL, OVERRELAX, VARIANT, 64>(p, do_tail, do_head);
+}
+template <int MODEL, bool OVERRELAX, int VARIANT>
+__global__ __launch_bounds__(256, 2) void klhr_stream16_kernel(const KParams p, const int do_tail, const int do_head) {
+    stream_body<MODEL, OVERRELAX, VARIANT, 16>(p, do_tail, do_head);
 }
 #pragma clang fp contract(fast)
 

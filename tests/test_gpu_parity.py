@@ -748,3 +748,28 @@ def test_handed_over_fits_equal_fits_finished_in_place(monkeypatch, kernel_mode,
     for o in out[1:]:
         for a, b in zip(out[0], o):
             assert np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.parametrize("name", ["funnel100", "illnormal100"])
+@pytest.mark.parametrize("variant,over,flags", [(0, False, {}), (0, True, {}), (1, False, {}), (2, False, {}),
+                                                (0, False, {"scale_dir_cov": True}), (0, False, {"eigen_method_one": True})])
+def test_paired_streaming_wavefronts_equal_single_wavefront(monkeypatch, kernel_mode, name, variant, over, flags):
+    """Split pipeline, 16-chain tiles: the streaming kernel runs a tile's tail and head on two wavefronts (RNG state handed
+    over in LDS after the MH draws, three workgroup barriers; klhr_split.hpp) — KLHR_STREAM_PAIR=0 runs them one after
+    the other on one wavefront.  120 draws cross both window closures of warmup = 100, where the head waits for the tail;
+    chain counts that leave the last tile / workgroup partly empty."""
+    if kernel_mode != "split":
+        pytest.skip("the streaming kernel of the split pipeline")
+    stem, data = model_spec(name)
+    for C in (203, 16, 33):
+        seeds = np.arange(C, dtype=np.uint64) + 5200
+        out = []
+        for mode in ("0", "1"):
+            monkeypatch.setenv("KLHR_STREAM_PAIR", mode)
+            s = make_sampler(stem, data, C, warmup=100, variant=variant, overrelaxed=over, **flags)
+            s.seed(seeds)
+            s.step(120, record_draws=True)
+            out.append([s.draws(0, 120)] + [s.get(f) for f in ("theta", "rng", "mean", "cov", "eigvecs", "eigvals", "om_m", "om_v", "pca_v",
+                                                                 "grad_evals", "acc", "counters", "status")])
+        for a, b in zip(out[0], out[1]):
+            assert np.array_equal(a, b, equal_nan=True)

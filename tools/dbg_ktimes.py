@@ -11,6 +11,7 @@ s = _lib.Sampler(_lib.MODEL_IDS[m], data, C, warmup=100)
 s.seed(np.arange(C, dtype=np.uint64)); s.step(150); s.sync()
 t0 = time.perf_counter(); s.step(50); s.sync(); t1 = time.perf_counter()
 print(f"{m}-{D} x {C}: {s.kernel_name()}  wall {1e6*(t1-t0)/50:.1f} us / iteration = {C*50/(t1-t0):.3e} it/s")
+if os.environ.get("DBG_WALL_ONLY"): sys.exit(0)
 s.kernel_profiling(True); s.step(20)
 names = s.kernel_names(); ms, n = s.kernel_times()
 for k, nm in enumerate(names): print(f"   {nm:20s} mean {1e3*ms[k]:9.1f} us x {n[k]} launches = {1e3*ms[k]*n[k]/20:9.1f} us / iteration (serialised)")
