@@ -90,10 +90,15 @@ KLHR_API int klhr_dim(const klhr_sampler *s);                  /* replaces BSMod
 KLHR_API int klhr_chains(const klhr_sampler *s);
 KLHR_API int klhr_sync(klhr_sampler *s);                       /* wait for the handle's stream */
 /* which hot-path kernels this handle launches: 0 = octet-per-chain (klhr_iter_kernel), 1 = lane-per-chain
- * (klhr_lane_kernel, model dimension <= 26), 2 = split-phase pipeline (klhr_stream_kernel + klhr_fit1_kernel +
- * klhr_fit2_kernel: funnel / ill-normal / normal above dimension 26).  Results agree within the stated tolerances;
- * only the mapping to the machine differs.  KLHR_KERNEL = octet | lane | mono | split in the environment overrides. */
+ * (klhr_lane_kernel, model dimension <= 26), 2 = split-phase pipeline (streaming kernel + klhr_fit1_kernel +
+ * klhr_fit2_kernel: funnel / ill-normal / normal above dimension 26), 3 = split-phase pipeline with both fit stages in
+ * the node-parallel klhr_fitn_kernel (up to 32 768 chains), 4 = as 2 with long KL fits handed to klhr_fit2r_kernel
+ * (KLHR_FIT_RESUME=1).  Results agree within the stated tolerances (2, 3, 4: bit for bit); only the mapping to the machine
+ * differs.  KLHR_KERNEL = octet | lane | mono | split in the environment overrides.
+ * klhr_tile_width: chains per tile of the split pipeline's state layout — 64 (klhr_stream_kernel) or 16
+ * (klhr_stream16_kernel, up to 16 384 chains); 0 for the monolithic kernels. */
 KLHR_API int klhr_kernel_variant(const klhr_sampler *s);
+KLHR_API int klhr_tile_width(const klhr_sampler *s);
 
 /* ---- seeding / initialisation --------------------------------------------------------------- */
 /* replaces: MCMCBase.__init__ (mcmc.py:4-17: default_rng(seed), D normals consumed unless a theta
@@ -213,7 +218,7 @@ KLHR_API int klhr_pool_fetch(klhr_sampler *s, double *out, size_t n_out);
 /* HIP-event time (ms) of the kernels launched by the most recent klhr_step on the handle's stream,
  * and the number of kernel launches it made.                                                      */
 KLHR_API int klhr_last_step_timing(klhr_sampler *s, double *kernel_ms, int *n_launches);
-/* Per-kernel timing for the roofline of bench.py.  The split-phase pipeline (klhr_kernel_variant == 2) runs three kernels per
+/* Per-kernel timing for the roofline of bench.py.  The split-phase pipeline (klhr_kernel_variant >= 2) runs two or three kernels per
  * iteration; with profiling enabled klhr_step runs its chains as one group and brackets every kernel with HIP events on the
  * handle's stream.  klhr_last_kernel_times: mean duration (ms) and launch count of [streaming kernel, mode-search kernel,
  * KL-fit kernel] over the most recent klhr_step (monolithic kernels: slot 0 = the hot kernel).                            */

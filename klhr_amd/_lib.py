@@ -55,6 +55,7 @@ def lib():
         "klhr_chains": (C.c_int, [vp]),
         "klhr_sync": (C.c_int, [vp]),
         "klhr_kernel_variant": (C.c_int, [vp]),
+        "klhr_tile_width": (C.c_int, [vp]),
         "klhr_seed": (C.c_int, [vp, u64p, C.c_int]),
         "klhr_seed_state": (None, [C.c_uint64, u64p]),
         "klhr_window_closures": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, i64p, C.c_int]),
@@ -99,7 +100,7 @@ def lib():
 
 
 EXPORTS = ["klhr_create", "klhr_destroy", "klhr_last_error", "klhr_abi_version", "klhr_device_count", "klhr_dim", "klhr_chains", "klhr_sync",
-           "klhr_kernel_variant",
+           "klhr_kernel_variant", "klhr_tile_width",
            "klhr_seed", "klhr_seed_state", "klhr_window_closures", "klhr_step", "klhr_get_draws", "klhr_reserve_draws", "klhr_random_direction",
            "klhr_fit", "klhr_metropolis", "klhr_adapt", "klhr_set_slice", "klhr_slice_step", "klhr_kl_eval", "klhr_line_eval", "klhr_log_density_gradient",
            "klhr_primitives", "klhr_get_state", "klhr_set_state", "klhr_mh_seed", "klhr_mh_step", "klhr_pool_stats",
@@ -214,10 +215,15 @@ class Sampler:
     def reserve_draws(self, n):
         self._ck(self._L.klhr_reserve_draws(self._h, int(n)), "klhr_reserve_draws")
 
+    def kernel_names(self):
+        """the hot-path kernels of this handle by name, in the slot order of kernel_times()"""
+        stream = "klhr_stream16_kernel" if self._L.klhr_tile_width(self._h) == 16 else "klhr_stream_kernel"
+        return {0: ["klhr_iter_kernel"], 1: ["klhr_lane_kernel"], 2: [stream, "klhr_fit1_kernel", "klhr_fit2_kernel"],
+                3: [stream, "(none)", "klhr_fitn_kernel"],
+                4: [stream, "klhr_fit1_kernel", "klhr_fit2_kernel+klhr_fit2r_kernel"]}[self._L.klhr_kernel_variant(self._h)]
+
     def kernel_name(self):
-        return {0: "klhr_iter_kernel", 1: "klhr_lane_kernel", 2: "klhr_stream_kernel+klhr_fit1_kernel+klhr_fit2_kernel",
-                3: "klhr_stream_kernel+klhr_fitn_kernel",
-                4: "klhr_stream_kernel+klhr_fit1_kernel+klhr_fit2_kernel+klhr_fit2r_kernel"}[self._L.klhr_kernel_variant(self._h)]
+        return "+".join(n for n in self.kernel_names() if n != "(none)")
 
     def draws(self, first=0, n=None, total=None):
         n = int(n)
@@ -234,11 +240,6 @@ class Sampler:
         n = (C.c_int * 3)()
         self._ck(self._L.klhr_last_kernel_times(self._h, ms, n), "klhr_last_kernel_times")
         return [ms[i] for i in range(3)], [n[i] for i in range(3)]
-
-    def kernel_names(self):
-        return {0: ["klhr_iter_kernel"], 1: ["klhr_lane_kernel"], 2: ["klhr_stream_kernel", "klhr_fit1_kernel", "klhr_fit2_kernel"],
-                3: ["klhr_stream_kernel", "(none)", "klhr_fitn_kernel"],
-                4: ["klhr_stream_kernel", "klhr_fit1_kernel", "klhr_fit2_kernel+klhr_fit2r_kernel"]}[self._L.klhr_kernel_variant(self._h)]
 
     def timing(self):
         ms = C.c_double()

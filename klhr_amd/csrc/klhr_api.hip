@@ -210,6 +210,7 @@ extern "C" int klhr_device_count(void) {
 extern "C" const char *klhr_last_error(const klhr_sampler *s) { return s ? s->err.c_str() : g_create_err.c_str(); }
 extern "C" int klhr_dim(const klhr_sampler *s) { return s ? s->D : KLHR_ERR_ARG; }
 extern "C" int klhr_chains(const klhr_sampler *s) { return s ? s->C : KLHR_ERR_ARG; }
+extern "C" int klhr_tile_width(const klhr_sampler *s) { return s ? (s->split ? s->tw : 0) : KLHR_ERR_ARG; }
 extern "C" int klhr_kernel_variant(const klhr_sampler *s) { return s ? (s->split ? (s->fitn ? 3 : (s->resume ? 4 : 2)) : (s->use_lane ? 1 : 0)) : KLHR_ERR_ARG; }
 
 // ---- host <-> device copies of [C][W] state arrays: the host side is always chain-major (the NumPy layout); the device
@@ -353,10 +354,11 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
     }
     if (s->split) s->use_lane = false;
     if (s->split) {
-        // Tile width of the streaming kernel: 64 lanes per tile use the whole wavefront, narrower tiles put more wavefronts —
-        // more loads in flight — on the machine.  The kernel is bound by memory latency, so: at least ~2 wavefronts per SIMD
-        // (2048 tiles) and at most ~24 KB of LDS column scratch per tile, down to 16 chains per tile.
-        int tw = (s->C + 63) / 64 < 1024 ? 16 : 64;
+        // Tile width of the streaming kernel: 64 lanes per tile use the whole wavefront; with few chains a launch lasts as long
+        // as one wavefront's walk through its phases whatever the width, and 16-chain tiles can run a tile's tail and head
+        // on two wavefronts (pair mode below, up to 16 384 chains).  Measured, ill-normal-100 (us per iteration, 16 | 64):
+        // 32 768 chains 299 | 270, 65 536: 642 | 420, 131 072: 1 114 | 644.
+        int tw = s->C <= 16384 ? 16 : 64;
         if (const char *e = getenv("KLHR_TILE")) { const int v = atoi(e); if (v == 16 || v == 64) tw = v; }
         if (((size_t)D * tw + 512) * 8 > 160 * 1024) tw = 16;       // (one column block + the tables must fit a CU's LDS)
         s->tw = tw;
@@ -407,7 +409,9 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
         // hands the unfinished fits (the thin long tail: funnel-100 median 13 passes, 1 % >= 28, rare 60-75) to the node-parallel
         // resume kernel.  Measured on funnel-100 x 131 072: KL fit 634 us -> 266 + 221 us (budget 14) with one chain group, but
         // 918 vs 920 us per iteration with the default four groups — the other groups' kernels already fill the SIMDs that a
-        // fit launch's tail leaves idle, and the tail's own latency (60 passes x 3 us) stays.  Off by default.
+        // fit launch's tail leaves idle, and the tail's own latency (60 passes x 3 us) stays.  (A second lane = chain launch over
+        // the compact hand-over list before the node-parallel one, budgets 22-32 / 10-16: 1.23-1.31e8 against 1.38e8 it/s — the
+        // 720-byte optimiser records written and read per handed-over chain cost more than the idle lanes.)  Off by default.
         TRY(dalloc(s, &k.resume_list, C)); TRY(dalloc(s, &k.resume_count, 16));
         TRY(hip_try(hipMemsetAsync(k.resume_count, 0, 16 * sizeof(unsigned int), s->stream), "hipMemsetAsync"));
         s->resume = false;
