@@ -79,3 +79,24 @@ def test_odd_chain_counts_every_variant(name):
                     first = th[0].copy()
                 else:
                     assert np.array_equal(th[0], first), (name, variant, over, C)
+
+
+def test_mapping_thresholds_do_not_show_in_a_chain():
+    """The split pipeline switches mappings with the chain count: 16-chain tiles with paired streaming wavefronts up to 16 384
+    chains, 64-chain tiles above; the node-parallel fit kernel up to 32 768 chains, the lane = chain fit kernels above.
+    The first chains' states after 60 draws (first window closure included) are the same bits on both sides of each threshold
+    and in a small launch."""
+    stem, data = model_spec("funnel100")
+    n, base = 60, 31000
+    ref = None
+    for C in (40, 16384, 16385, 32768, 32769):
+        s = make_sampler(stem, data, C, warmup=100)
+        s.seed(np.arange(C, dtype=np.uint64) + base)
+        s.step(n)
+        assert not s.get("status").any(), C
+        st = [s.get(f)[:40] for f in ("theta", "rng", "cov", "eigvecs", "pca_v", "acc", "grad_evals", "counters")]
+        if ref is None:
+            ref = st
+        else:
+            for a, b in zip(ref, st):
+                assert np.array_equal(a, b), (C, s.kernel_name())
