@@ -93,7 +93,8 @@ KLHR_API int klhr_sync(klhr_sampler *s);                       /* wait for the h
  * (klhr_lane_kernel, model dimension <= 26), 2 = split-phase pipeline (streaming kernel + klhr_fit1_kernel +
  * klhr_fit2_kernel: funnel / ill-normal / normal above dimension 26), 3 = split-phase pipeline with both fit stages in
  * the node-parallel klhr_fitn_kernel (up to 32 768 chains), 4 = as 2 with long KL fits handed to klhr_fit2r_kernel
- * (KLHR_FIT_RESUME=1).  Results agree within the stated tolerances (2, 3, 4: bit for bit); only the mapping to the machine
+ * (KLHR_FIT_RESUME=1), 5 = as 3, and klhr_step runs whole iterations per 16-chain tile in one launch (klhr_tile_kernel,
+ * up to 8 192 chains; the pieces of the C ABI and diagnostic steps use the kernels of 3).  Results agree within the stated tolerances (2, 3, 4, 5: bit for bit); only the mapping to the machine
  * differs.  KLHR_KERNEL = octet | lane | mono | split in the environment overrides.
  * klhr_tile_width: chains per tile of the split pipeline's state layout — 64 (klhr_stream_kernel) or 16
  * (klhr_stream16_kernel, up to 16 384 chains); 0 for the monolithic kernels. */

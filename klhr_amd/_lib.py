@@ -220,7 +220,8 @@ class Sampler:
         stream = "klhr_stream16_kernel" if self._L.klhr_tile_width(self._h) == 16 else "klhr_stream_kernel"
         return {0: ["klhr_iter_kernel"], 1: ["klhr_lane_kernel"], 2: [stream, "klhr_fit1_kernel", "klhr_fit2_kernel"],
                 3: [stream, "(none)", "klhr_fitn_kernel"],
-                4: [stream, "klhr_fit1_kernel", "klhr_fit2_kernel+klhr_fit2r_kernel"]}[self._L.klhr_kernel_variant(self._h)]
+                4: [stream, "klhr_fit1_kernel", "klhr_fit2_kernel+klhr_fit2r_kernel"],
+                5: ["klhr_tile_kernel"]}[self._L.klhr_kernel_variant(self._h)]
 
     def kernel_name(self):
         return "+".join(n for n in self.kernel_names() if n != "(none)")

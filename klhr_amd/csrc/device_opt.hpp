@@ -51,6 +51,16 @@ static inline double mul_rn(double a, double b) { return a * b; }
 static inline double sub_rn(double a, double b) { return a - b; }
 #endif
 
+// The optimiser is inlined into several kernels that must agree bit for bit (the split pipeline's lane = chain and node-parallel
+// fit kernels: a chain's draws may not depend on the launch size).  Under the default -ffp-contract=fast the backend fuses a
+// multiplication with an addition wherever it finds the pair after inlining — a decision that depends on the surrounding code
+// (seen: the same inputs gave a request point one ulp apart in klhr_fit2_kernel and klhr_fitn_kernel, 1 chain-draw in ~2 000).
+// contract(on) forms the FMAs in the front end, within an expression, the same way wherever the function is inlined.
+// (The host-compiled parity harness keeps its -ffp-contract=off.)
+#ifndef KLHR_HOST_HARNESS
+#pragma clang fp contract(on)
+#endif
+
 enum { PC_INIT = 0, PC_W1 = 1, PC_W2 = 2, PC_ZOOM = 3, PC_DONE = 4 };
 
 // line-search scratch, overlaid: DCSRCH state and wolfe2/zoom state are never live together
@@ -486,3 +496,6 @@ __device__ inline void opt_advance(Opt &o, double f, const double *g) {
 }
 
 }  // namespace klhr
+#ifndef KLHR_HOST_HARNESS
+#pragma clang fp contract(fast)
+#endif

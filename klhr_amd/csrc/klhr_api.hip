@@ -101,6 +101,8 @@ struct klhr_sampler {
     bool async_ok = false;       // klhr_step lets chains progress asynchronously (split pipeline)
     bool fitn = false;           // split pipeline: both fit stages in the node-parallel kernel (few chains: klhr_fitn_kernel)
     bool resume = false;         // split pipeline, many chains: long KL fits are handed to the node-parallel resume kernel
+    bool last_fused = false;     // the most recent klhr_step ran as one klhr_tile_kernel launch
+    bool fused = false;          // split pipeline, few chains: whole iterations per tile in one launch (klhr_tile_kernel)
     unsigned int *h_pend = nullptr;      // pinned host copy of the groups' pending-chain counters
     bool profile = false;
     std::vector<hipEvent_t> pev;
@@ -211,7 +213,7 @@ extern "C" const char *klhr_last_error(const klhr_sampler *s) { return s ? s->er
 extern "C" int klhr_dim(const klhr_sampler *s) { return s ? s->D : KLHR_ERR_ARG; }
 extern "C" int klhr_chains(const klhr_sampler *s) { return s ? s->C : KLHR_ERR_ARG; }
 extern "C" int klhr_tile_width(const klhr_sampler *s) { return s ? (s->split ? s->tw : 0) : KLHR_ERR_ARG; }
-extern "C" int klhr_kernel_variant(const klhr_sampler *s) { return s ? (s->split ? (s->fitn ? 3 : (s->resume ? 4 : 2)) : (s->use_lane ? 1 : 0)) : KLHR_ERR_ARG; }
+extern "C" int klhr_kernel_variant(const klhr_sampler *s) { return s ? (s->split ? (s->fused ? 5 : (s->fitn ? 3 : (s->resume ? 4 : 2))) : (s->use_lane ? 1 : 0)) : KLHR_ERR_ARG; }
 
 // ---- host <-> device copies of [C][W] state arrays: the host side is always chain-major (the NumPy layout); the device
 // side is tiled [tile][w][64 lanes] for handles of the split pipeline
@@ -419,6 +421,11 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
         k.resume_budget = 16;
         if (const char *e = getenv("KLHR_FIT_RESUME_BUDGET")) { const int v = atoi(e); if (v >= 1) k.resume_budget = v; }
         if (!s->resume) k.resume_budget = 0;
+        // few chains: klhr_step runs whole iterations per 16-chain tile in ONE launch (klhr_tile_kernel: the pair-mode streaming
+        // body and the node-parallel fit body in a loop over the draws, one workgroup per tile).  Needs what those two need.
+        // One wavefront per SIMD by register count: up to 8 192 chains (1 024 wavefronts); measured in klhr_split.hpp.
+        s->fused = s->tw == 16 && s->fitn && s->C <= 8192 && ((size_t)2 * D * 16 + 512 + 65) * 8 <= 160 * 1024;
+        if (const char *e = getenv("KLHR_FUSED")) s->fused = s->fused && atoi(e) != 0;
         if (const char *e = getenv("KLHR_FIT_BUDGET1")) { const int v = atoi(e); if (v >= 1) k.budget1 = v; }
         if (const char *e = getenv("KLHR_FIT_BUDGET2")) { const int v = atoi(e); if (v >= 1) k.budget2 = v; }
         // Chain groups of klhr_step: the streaming kernel is bound by memory, the fit kernels by the fp64 ALUs; with the chains
@@ -576,6 +583,23 @@ static int run_phases(klhr_sampler *s, int phases, int64_t n_iters, int record_d
     if (!s->seeded && (phases & (PH_DIR | PH_FIT | PH_MH))) { s->err = "klhr: chains are not seeded (call klhr_seed or set RNG/theta state)"; return KLHR_ERR_STATE; }
     HIPCHECK(s, hipSetDevice(s->cfg.device));
     if (record_draws) { int rc = ensure_draws(s, n_iters); if (rc) return rc; s->draws_iters = n_iters; }
+    if (s->split && s->fused && phases == PH_ALL && !record_diag) {
+        KParams kp = s->kp;
+        kp.phases = phases;
+        kp.n_iters = (int)n_iters;
+        kp.async_mode = 0;
+        kp.resume_budget = 0;
+        kp.draws = record_draws ? s->d_draws : nullptr;
+        HIPCHECK(s, hipEventRecord(s->ev0, s->stream));
+        launch_split(s, kp, 7, 1, 1, s->stream);
+        HIPCHECK(s, hipGetLastError());
+        HIPCHECK(s, hipEventRecord(s->ev1, s->stream));
+        s->timing_pending = true;
+        s->last_launches = 1;
+        s->last_fused = true;
+        return KLHR_OK;
+    }
+    s->last_fused = false;
     if (s->split) {
         // Split-phase pipeline (klhr_split.hpp).  Iteration k = [stream kernel: tail of k-1 (MH, adaptation, draw output) +
         // head of k (direction, line sums, the fit's normals)] -> mode-search kernel -> KL-fit kernel; one last stream launch
@@ -748,7 +772,7 @@ extern "C" int klhr_set_kernel_profiling(klhr_sampler *s, int enable) {
 extern "C" int klhr_last_kernel_times(klhr_sampler *s, double ms3[3], int n3[3]) {
     if (!s || !ms3 || !n3) return KLHR_ERR_ARG;
     for (int k = 0; k < 3; k++) { ms3[k] = 0; n3[k] = 0; }
-    if (!s->split) {
+    if (!s->split || s->last_fused) {
         double ms = 0; int nl = 0;
         int rc = klhr_last_step_timing(s, &ms, &nl);
         if (rc) return rc;

@@ -341,6 +341,8 @@ __device__ __forceinline__ void lane_eval_line(const KParams &p, const double2 *
 // of _logp_grad (klhr_sinh.py:158-161) is inactive whenever max_i |g_i(t)| <= clip, which max|a|, max|r| bound; the rare point
 // where the bound fails (measured on the reference: 1 in 2 000-5 000 KL evaluations) is recomputed by the element-wise loop.
 // Used by this kernel for D <= 26 and by the split-phase pipeline (klhr_split.hpp) above that.
+// (contract(on): FMAs are formed per expression in the front end — line_point is inlined into kernels that must agree bit for bit)
+#pragma clang fp contract(on)
 struct LineStat { double v0, r0, A, B, C, m0, m1; };
 
 #define KLHR_FB(p, f, c) (p).fitbuf[(long long)(f) * (p).fstride + (c)]

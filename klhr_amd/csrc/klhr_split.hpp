@@ -275,6 +275,9 @@ __global__ __launch_bounds__(64) void klhr_fit2_kernel(const KParams p) {
             if (opt_cache_hit(o)) { f = o.lf; g[0] = o.lg[0]; g[1] = o.lg[1]; g[2] = o.lg[2]; g[3] = o.lg[3]; }
             else {
                 split_eval_kl<MODEL, VARIANT>(p, st, task, nn, o.xt, f, g);
+#ifdef KLHR_DBG_CHAIN
+                if (task == KLHR_DBG_CHAIN) printf("L pass %d x %a %a %a %a f %a g %a %a %a %a\n", npass, o.xt[0], o.xt[1], o.xt[2], o.xt[3], f, g[0], g[1], g[2], g[3]);
+#endif
                 opt_cache_store(o, f, g);
                 npass++;
             }
@@ -359,10 +362,8 @@ __device__ __forceinline__ void node_eval_kl(const KParams &p, const LineStat &s
 #pragma clang fp contract(fast)
 
 template <int MODEL, int VARIANT>
-__global__ __launch_bounds__(64) void klhr_fitn_kernel(const KParams p) {
+__device__ __forceinline__ void fitn_body(const KParams &p, const long long task, const int l8) {
     constexpr int N = VARIANT == VAR_GAUSS ? 2 : (VARIANT == VAR_SUB ? 3 : 4);
-    const int lane = threadIdx.x & 63, l8 = lane & 7;
-    const long long task = (long long)blockIdx.x * 8 + (lane >> 3);
     if (task >= p.C) return;                    // (whole octets leave: the butterflies stay inside an octet)
     const bool diag = (p.flags & FLAG_DIAG) != 0, lead = l8 == 0;
     // this lane's quadrature node (a per-lane index into the kernel-argument tables would go through scratch)
@@ -428,6 +429,9 @@ __global__ __launch_bounds__(64) void klhr_fitn_kernel(const KParams p) {
             if (opt_cache_hit(o)) { f = o.lf; g[0] = o.lg[0]; g[1] = o.lg[1]; g[2] = o.lg[2]; g[3] = o.lg[3]; }
             else {
                 node_eval_kl<MODEL, VARIANT>(p, st, task, nn, o.xt, q_a, q_x, q_w, f, g);
+#ifdef KLHR_DBG_CHAIN
+                if (task == KLHR_DBG_CHAIN && l8 == 0) printf("N pass %d x %a %a %a %a f %a g %a %a %a %a\n", npass, o.xt[0], o.xt[1], o.xt[2], o.xt[3], f, g[0], g[1], g[2], g[3]);
+#endif
                 opt_cache_store(o, f, g);
                 npass++;
             }
@@ -445,6 +449,12 @@ __global__ __launch_bounds__(64) void klhr_fitn_kernel(const KParams p) {
             dd[KLHR_D_FALLBACKS] = fb1 + o.fallbacks; dd[KLHR_D_PASSES] = npass1 + npass;
         }
     }
+}
+
+template <int MODEL, int VARIANT>
+__global__ __launch_bounds__(64) void klhr_fitn_kernel(const KParams p) {
+    const int lane = threadIdx.x & 63;
+    fitn_body<MODEL, VARIANT>(p, (long long)blockIdx.x * 8 + (lane >> 3), lane & 7);
 }
 
 // The KL fits that klhr_fit2_kernel handed over (KParams::resume_budget): node-parallel from the saved optimiser state on.
@@ -723,14 +733,15 @@ __device__ __forceinline__ void line_accumulate(const KParams &p, int i, double 
 // B's direction pass goes before b3 unless a chain of the workgroup closes a window.  Every chain's arithmetic is the
 // single-wavefront form's, operation for operation.
 template <int MODEL, bool OVERRELAX, int VARIANT, int W>
-__device__ __forceinline__ void stream_body(const KParams &p, const int do_tail, const int do_head) {
+__device__ __forceinline__ void stream_body(const KParams &p, const int do_tail, const int do_head, const int draw_slot, const unsigned bid,
+                                            const unsigned tid) {      // bid / tid: blockIdx.x / threadIdx.x (klhr_tile_kernel passes them through an optimisation barrier)
     extern __shared__ double lds[];            // [waves][D][W] column scratch (normals, then theta - mean), then the ziggurat tables
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = tid & 63, wv = tid >> 6;
     const bool pair = p.stream_pair != 0;
     const int role = pair ? (wv & 1) : 2;                       // 0: the tile's tail, 1: the tile's head, 2: both (one wavefront per tile)
     const int tslot = pair ? wv >> 1 : wv;                      // the workgroup's tile this wavefront works on
     const int tiles_wg = pair ? p.stream_waves >> 1 : p.stream_waves;
-    const long long tile = (long long)blockIdx.x * tiles_wg + tslot;
+    const long long tile = (long long)bid * tiles_wg + tslot;
     const long long c = tile * W + lane;
     const int D = p.D, nc = p.ncol, K = p.J;
     double *Z = lds + (size_t)tslot * (pair ? 2 : 1) * D * W + lane;       // tail: u = theta' - mean
@@ -741,8 +752,8 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
     unsigned long long *hand = reinterpret_cast<unsigned long long *>(zwi + 512) + (size_t)tslot * 4 * W + lane;
     int *closing = reinterpret_cast<int *>(zwi + 512 + (size_t)tiles_wg * 4 * W);
     if ((do_head && (p.phases & PH_DIR)) || pair) {
-        for (int i = threadIdx.x; i < 256; i += blockDim.x) { zwi[i] = KLHR_ZIG_WI[i]; zki[i] = KLHR_ZIG_KI[i]; }
-        if (pair && threadIdx.x == 0) *closing = 0;
+        for (int i = tid; i < 256; i += blockDim.x) { zwi[i] = KLHR_ZIG_WI[i]; zki[i] = KLHR_ZIG_KI[i]; }
+        if (pair && tid == 0) *closing = 0;
         __syncthreads();
     }
     // (a wavefront whose tile lies beyond the last chain ends here; s_barrier waits for the surviving wavefronts only)
@@ -842,7 +853,7 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
     double u_choice = 0.0, ssq = 0.0;
     if (tail_here) {
         // recorded draws: slot = the chain's own draw index within this call (chains may be rounds apart in async mode)
-        long long slot = (long long)p.draw_slot;
+        long long slot = (long long)draw_slot;
         if (p.async_mode) { const int tg = p.togo[c]; slot = (long long)p.n_iters - tg; p.togo[c] = tg - 1; }
         double *out = p.draws ? p.draws + slot * p.draw_stride + c * D : nullptr;
         // ---- pass T1: theta' = a (theta + zp rho) + (1 - a) theta; OnlineMoments(theta'); Z = theta' - mean
@@ -1076,11 +1087,37 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
 // 16-chain tiles (two wavefronts per SIMD)
 template <int MODEL, bool OVERRELAX, int VARIANT>
 __global__ __launch_bounds__(256) void klhr_stream_kernel(const KParams p, const int do_tail, const int do_head) {
-    stream_body<MODEL, OVERRELAX, VARIANT, 64>(p, do_tail, do_head);
+    stream_body<MODEL, OVERRELAX, VARIANT, 64>(p, do_tail, do_head, p.draw_slot, blockIdx.x, threadIdx.x);
 }
 template <int MODEL, bool OVERRELAX, int VARIANT>
 __global__ __launch_bounds__(256, 2) void klhr_stream16_kernel(const KParams p, const int do_tail, const int do_head) {
-    stream_body<MODEL, OVERRELAX, VARIANT, 16>(p, do_tail, do_head);
+    stream_body<MODEL, OVERRELAX, VARIANT, 16>(p, do_tail, do_head, p.draw_slot, blockIdx.x, threadIdx.x);
+}
+// Few chains (up to 8 192): WHOLE ITERATIONS of a tile in one workgroup, all the draws of a call in one launch.  A tile of 16
+// chains is two wavefronts in the streaming part (pair mode: tail | head) and two wavefronts in the fit (8 lanes per chain, 8
+// chains per wavefront), and nothing of an iteration crosses tiles — so the workgroup loops over the iterations on its own:
+// no launch boundaries, no wait for the slowest chain of the whole launch (a tile waits for the slowest of its 16), and tiles
+// drift apart, so that some stream (memory) while others fit (ALU).  Streaming and fit code are the kernels' own bodies.
+// One wavefront per SIMD (336 registers, no scratch; built for two it spills 90 registers and is slower than the kernel
+// sequence): 8 192 chains = 512 tiles = 1 024 wavefronts fill the machine once.  ill-normal-100, us per iteration, kernel
+// sequence | this kernel: 2 048 chains 137 | 110, 4 096: 145 | 109, 8 192: 154 | 111 (16 384: 160 | 221, a second round).
+template <int MODEL, bool OVERRELAX, int VARIANT>
+__global__ __launch_bounds__(128) void klhr_tile_kernel(const KParams p) {
+#pragma unroll 1
+    for (int it = 0; it <= p.n_iters; it++) {
+        // (the indices go through an empty asm per iteration: everything derived from them — a dozen row addresses, the node
+        //  constants — is then recomputed per iteration instead of being kept alive across both bodies)
+        unsigned bid = blockIdx.x, tid = threadIdx.x;
+        asm volatile("" : "+s"(bid));
+        asm volatile("" : "+v"(tid));
+        stream_body<MODEL, OVERRELAX, VARIANT, 16>(p, it > 0, it < p.n_iters, it - 1, bid, tid);
+        __syncthreads();                 // line sums, norm and the fit's normals of every chain of the tile are in HBM
+        asm volatile("" : "+s"(bid));
+        asm volatile("" : "+v"(tid));
+        const long long task = (long long)bid * 16 + (tid >> 6) * 8 + ((tid & 63) >> 3);
+        if (it < p.n_iters) fitn_body<MODEL, VARIANT>(p, task, tid & 7);
+        __syncthreads();                 // eta and the evaluation counts are in HBM
+    }
 }
 #pragma clang fp contract(fast)
 

@@ -47,7 +47,7 @@ def test_instantiation_matches_oracle(oracle, monkeypatch, kernel_mode, name, la
     for kernel in kernels:
         monkeypatch.setenv("KLHR_KERNEL", kernel)
         s = make_sampler(stem, data, NCHAINS, variant=variant, **kw)
-        assert ("lane" in s.kernel_name()) == (kernel == "lane") and ("stream" in s.kernel_name()) == (kernel == "split"), s.kernel_name()
+        assert ("lane" in s.kernel_name()) == (kernel == "lane") and ("stream" in s.kernel_name() or "tile" in s.kernel_name()) == (kernel == "split"), s.kernel_name()
         s.seed(seeds)
         s.step(NDRAWS, record_draws=True)
         got = s.draws(0, NDRAWS)

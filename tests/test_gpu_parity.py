@@ -330,7 +330,9 @@ def test_iterations_per_launch_and_reserved_buffer_do_not_change_results(monkeyp
             s.reserve_draws(120)
         s.step(120, record_draws=True)
         out.append((s.draws(0, 120), s.get("theta"), s.get("rng"), s.get("cov"), s.timing()[1]))
-    if "stream" in s.kernel_name():
+    if "tile" in s.kernel_name():
+        assert out[0][4] == out[1][4] == out[2][4] == 1                    # whole iterations per tile: the call is one launch
+    elif "stream" in s.kernel_name():
         assert out[0][4] == out[1][4] == out[2][4] == 120                  # split pipeline: one launch group per iteration, KLHR_CHUNK has no meaning
     else:
         assert out[0][4] == 1 and out[1][4] == 18 and out[2][4] == 3      # launches: 120 in one / ceil(120/7) / ceil(120/50)
@@ -714,6 +716,7 @@ def test_node_parallel_fit_equals_lane_per_chain_fit(monkeypatch, kernel_mode, n
     seeds = np.arange(C, dtype=np.uint64) + 4100
     for clips in ({}, {"grad_clip": 3.0, "scale_clip": 3.0}):
         out = []
+        monkeypatch.setenv("KLHR_FUSED", "0")
         for mode in ("0", "1"):
             monkeypatch.setenv("KLHR_FITN", mode)
             s = make_sampler(stem, data, C, warmup=100, variant=variant, overrelaxed=over, **clips)
@@ -764,6 +767,7 @@ def test_paired_streaming_wavefronts_equal_single_wavefront(monkeypatch, kernel_
     for C in (203, 16, 33):
         seeds = np.arange(C, dtype=np.uint64) + 5200
         out = []
+        monkeypatch.setenv("KLHR_FUSED", "0")
         for mode in ("0", "1"):
             monkeypatch.setenv("KLHR_STREAM_PAIR", mode)
             s = make_sampler(stem, data, C, warmup=100, variant=variant, overrelaxed=over, **flags)
@@ -772,4 +776,56 @@ def test_paired_streaming_wavefronts_equal_single_wavefront(monkeypatch, kernel_
             out.append([s.draws(0, 120)] + [s.get(f) for f in ("theta", "rng", "mean", "cov", "eigvecs", "eigvals", "om_m", "om_v", "pca_v",
                                                                  "grad_evals", "acc", "counters", "status")])
         for a, b in zip(out[0], out[1]):
+            assert np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.parametrize("name", ["funnel100", "illnormal100", "funnel10"])
+@pytest.mark.parametrize("variant,over,flags", [(0, False, {}), (0, True, {}), (1, False, {}), (2, True, {}),
+                                                (0, False, {"scale_dir_cov": True}), (0, False, {"eigen_method_one": True})])
+def test_whole_iterations_per_tile_equal_the_kernel_sequence(monkeypatch, kernel_mode, name, variant, over, flags):
+    """Split pipeline, up to 16 384 chains: klhr_step runs all draws of a call in ONE launch, a workgroup looping over the
+    iterations of its 16-chain tile (klhr_tile_kernel: the streaming body in pair mode, then the node-parallel fit body);
+    KLHR_FUSED=0 runs the same bodies as a sequence of launches.  Two calls of 70 and 50 draws (the second one starts with a
+    head on a state the first one left), recorded draws, chain counts that leave a tile partly empty."""
+    if kernel_mode != "split":
+        pytest.skip("the split pipeline")
+    stem, data = model_spec(name)
+    for C in (203, 16, 33):
+        seeds = np.arange(C, dtype=np.uint64) + 6400
+        out = []
+        for mode in ("0", "1"):
+            monkeypatch.setenv("KLHR_FUSED", mode)
+            s = make_sampler(stem, data, C, warmup=100, variant=variant, overrelaxed=over, **flags)
+            assert ("tile" in s.kernel_name()) == (mode == "1"), s.kernel_name()
+            s.seed(seeds)
+            s.step(70, record_draws=True)
+            d1 = s.draws(0, 70)
+            s.step(50, record_draws=True)
+            out.append([d1, s.draws(0, 50)] + [s.get(f) for f in ("theta", "rng", "mean", "cov", "eigvecs", "eigvals", "om_m", "om_v", "pca_v",
+                                                                    "grad_evals", "acc", "counters", "status")])
+        for a, b in zip(out[0], out[1]):
+            assert np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.parametrize("name", ["funnel100", "illnormal100"])
+def test_fit_kernel_forms_agree_over_a_population(monkeypatch, kernel_mode, name):
+    """2 048 chains x 30 draws through the lane = chain fit kernels, the node-parallel fit kernel and the whole-iterations-per-tile
+    kernel: the same bits.  (With the optimiser compiled under -ffp-contract=fast the back end fused a multiplication and an
+    addition in one inlined copy and not in the other: one chain-draw in ~2 000 got a request point one ulp apart — too rare
+    for the 203-chain tests above, so this one looks at a population.)"""
+    if kernel_mode != "split":
+        pytest.skip("the fit kernels of the split pipeline")
+    stem, data = model_spec(name)
+    C = 2048
+    seeds = np.arange(C, dtype=np.uint64) + 1000
+    out = []
+    for fitn, fused in (("0", "0"), ("1", "0"), ("1", "1")):
+        monkeypatch.setenv("KLHR_FITN", fitn)
+        monkeypatch.setenv("KLHR_FUSED", fused)
+        s = make_sampler(stem, data, C, warmup=100)
+        s.seed(seeds)
+        s.step(30)
+        out.append([s.get(f) for f in ("theta", "rng", "eta", "pca_v", "grad_evals", "acc")])
+    for o in out[1:]:
+        for a, b in zip(out[0], o):
             assert np.array_equal(a, b, equal_nan=True)
