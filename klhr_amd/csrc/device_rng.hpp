@@ -12,6 +12,8 @@
 #define KLHR_ZIG_QUAL static __device__ const
 #include "zig_tables.h"
 
+// NumPy's generator code is plain C without FMA contraction: every operation here rounds on its own
+#pragma clang fp contract(off)
 namespace klhr {
 
 typedef unsigned __int128 u128;
@@ -193,3 +195,4 @@ __device__ inline double rng_std_exponential(Pcg64 &g) {
 }
 
 }  // namespace klhr
+#pragma clang fp contract(fast)

@@ -124,7 +124,9 @@ __device__ __forceinline__ double grp_sum8(double v) {
     v += dpp_move(v, 2);     // row_half_mirror: lane i <-> 7-i of its 8-lane half row
     return v;
 }
-#pragma clang fp contract(fast)
+// (contract(on): FMAs formed per expression in the front end, the same way in every kernel these helpers are inlined into;
+//  under contract(fast) the back end's fusion depends on the inlining context — see device_opt.hpp)
+#pragma clang fp contract(on)
 
 // sinh-arcsinh helpers (klhr_sinh.py:78-84): s = exp(clip(eta1)) + tol, d = exp(clip(eta2)) + tol
 // sub == true: SUBKLHRSINH's 3-parameter form, d == 1 and e = eta[2] (sub_klhr_sinh.py:92-97)
