@@ -424,8 +424,9 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
         // few chains: klhr_step runs whole iterations per 16-chain tile in ONE launch (klhr_tile_kernel: the pair-mode streaming
         // body and the node-parallel fit body in a loop over the draws, one workgroup per tile).  Needs what those two need.
         // One wavefront per SIMD by register count: up to 8 192 chains (1 024 wavefronts); measured in klhr_split.hpp.
-        s->fused = s->tw == 16 && s->fitn && s->C <= 8192 && ((size_t)2 * D * 16 + 512 + 65) * 8 <= 160 * 1024;
-        if (const char *e = getenv("KLHR_FUSED")) s->fused = s->fused && atoi(e) != 0;
+        const bool fused_ok = s->tw == 16 && s->fitn && ((size_t)2 * D * 16 + 512 + 65) * 8 <= 160 * 1024;
+        s->fused = fused_ok && s->C <= 8192;
+        if (const char *e = getenv("KLHR_FUSED")) s->fused = atoi(e) == 2 ? fused_ok : (s->fused && atoi(e) != 0);      // (2: whatever the chain count)
         if (const char *e = getenv("KLHR_FIT_BUDGET1")) { const int v = atoi(e); if (v >= 1) k.budget1 = v; }
         if (const char *e = getenv("KLHR_FIT_BUDGET2")) { const int v = atoi(e); if (v >= 1) k.budget2 = v; }
         // Chain groups of klhr_step: the streaming kernel is bound by memory, the fit kernels by the fp64 ALUs; with the chains

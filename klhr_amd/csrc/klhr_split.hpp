@@ -1102,7 +1102,10 @@ __global__ __launch_bounds__(256, 2) void klhr_stream16_kernel(const KParams p, 
 // sequence): 8 192 chains = 512 tiles = 1 024 wavefronts fill the machine once.  ill-normal-100, us per iteration, kernel
 // sequence | this kernel: 2 048 chains 137 | 110, 4 096: 145 | 109, 8 192: 154 | 111 (16 384: 160 | 221, a second round).
 template <int MODEL, bool OVERRELAX, int VARIANT>
-__global__ __launch_bounds__(128) void klhr_tile_kernel(const KParams p) {
+#ifndef KLHR_TILE_WAVES
+#define KLHR_TILE_WAVES 1
+#endif
+__global__ __launch_bounds__(128, KLHR_TILE_WAVES) void klhr_tile_kernel(const KParams p) {
 #pragma unroll 1
     for (int it = 0; it <= p.n_iters; it++) {
         // (the indices go through an empty asm per iteration: everything derived from them — a dozen row addresses, the node
