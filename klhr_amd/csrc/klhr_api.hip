@@ -585,18 +585,25 @@ static int run_phases(klhr_sampler *s, int phases, int64_t n_iters, int record_d
     HIPCHECK(s, hipSetDevice(s->cfg.device));
     if (record_draws) { int rc = ensure_draws(s, n_iters); if (rc) return rc; s->draws_iters = n_iters; }
     if (s->split && s->fused && phases == PH_ALL && !record_diag) {
-        KParams kp = s->kp;
-        kp.phases = phases;
-        kp.n_iters = (int)n_iters;
-        kp.async_mode = 0;
-        kp.resume_budget = 0;
-        kp.draws = record_draws ? s->d_draws : nullptr;
+        // (a launch is kept to a few tens of milliseconds: 256 draws; a call of more draws is a sequence of launches, each
+        //  ending with the tail of its last draw — the same as consecutive calls)
+        const int64_t chunk = 256;
         HIPCHECK(s, hipEventRecord(s->ev0, s->stream));
-        launch_split(s, kp, 7, 1, 1, s->stream);
-        HIPCHECK(s, hipGetLastError());
+        int launches = 0;
+        for (int64_t done = 0; done < n_iters; done += chunk) {
+            KParams kp = s->kp;
+            kp.phases = phases;
+            kp.n_iters = (int)((n_iters - done) < chunk ? (n_iters - done) : chunk);
+            kp.async_mode = 0;
+            kp.resume_budget = 0;
+            kp.draws = record_draws ? s->d_draws + (size_t)done * s->C * s->D : nullptr;
+            launch_split(s, kp, 7, 1, 1, s->stream);
+            HIPCHECK(s, hipGetLastError());
+            launches++;
+        }
         HIPCHECK(s, hipEventRecord(s->ev1, s->stream));
         s->timing_pending = true;
-        s->last_launches = 1;
+        s->last_launches = launches;
         s->last_fused = true;
         return KLHR_OK;
     }
