@@ -339,7 +339,10 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
     s->S_lane = SL;
     s->use_lane = (D <= 26) && (((size_t)64 * SL + 1072) * 8 <= 64 * 1024);   // + LANE_LDS_EXTRA (klhr_lane_kernel.hpp)
     // split-phase pipeline: line-separable targets, any variant but the slice sampler; one [D][64] LDS column block per tile
-    const bool split_ok = (cfg->model_id == KLHR_MODEL_FUNNEL || cfg->model_id == KLHR_MODEL_ILL_NORMAL || cfg->model_id == KLHR_MODEL_NORMAL) &&
+    // (ar1: its z-transform is linear on a line, so the same closed form applies; the element-wise gradient that scale_dir_cov
+    //  tracks needs a coordinate's neighbours, which the streaming kernel's per-element pass does not carry: octet kernel then)
+    const bool split_ok = (cfg->model_id == KLHR_MODEL_FUNNEL || cfg->model_id == KLHR_MODEL_ILL_NORMAL || cfg->model_id == KLHR_MODEL_NORMAL ||
+                           (cfg->model_id == KLHR_MODEL_AR1 && !cfg->scale_dir_cov)) &&
                           cfg->variant != 3 && ((size_t)D * 16 + 512) * 8 <= 64 * 1024;
     // default: the lane-per-chain kernel while a chain's row fits its LDS share (D <= 26), the split pipeline above that for
     // the separable targets, the octet kernel for everything else.  KLHR_KERNEL = octet | lane | mono | split overrides

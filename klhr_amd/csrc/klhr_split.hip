@@ -72,6 +72,7 @@ void KLHR_CAT2(launch_split_v, KLHR_VARIANT)(const KParams &kp, int model_id, in
     switch (model_id) {
     case KLHR_MODEL_FUNNEL: launch_split_model<MODEL_FUNNEL>(kp, what, overrelaxed, do_tail, do_head, stream); break;
     case KLHR_MODEL_ILL_NORMAL: launch_split_model<MODEL_ILL_NORMAL>(kp, what, overrelaxed, do_tail, do_head, stream); break;
+    case KLHR_MODEL_AR1: launch_split_model<MODEL_AR1>(kp, what, overrelaxed, do_tail, do_head, stream); break;
     default: launch_split_model<MODEL_NORMAL>(kp, what, overrelaxed, do_tail, do_head, stream); break;
     }
 }

@@ -59,6 +59,29 @@ __device__ __attribute__((noinline)) Pts4 exact_points4(const double *theta_t, c
             o.gd[n] = clipc(g0, cl) * r0 + gd[n];
             o.lp[n] = -v[n] * v[n] * (1.0 / 18.0) - 0.5 * Da * v[n] - 0.5 * ev[n] * ss[n];
         }
+    } else if constexpr (MODEL == MODEL_AR1) {
+        // model_eval's chained pass (device_models.hpp): g_{i-1} is complete once z_i is known
+        const double a = 0.9, b = sqrt(1 - a * a);
+        double rp = r_t[0] / nn;
+        double xp[4], lp[4], gprev[4], gd[4];
+#pragma unroll
+        for (int n = 0; n < 4; n++) { xp[n] = fma(t[n], rp, theta_t[0]); lp[n] = -0.5 * xp[n] * xp[n]; gprev[n] = -xp[n]; gd[n] = 0.0; }
+        for (int i = 1; i < D; i++) {
+            const double th = theta_t[(long long)i * W], r = r_t[(long long)i * W] / nn;
+#pragma unroll
+            for (int n = 0; n < 4; n++) {
+                const double xi = fma(t[n], r, th);
+                const double z = (xi - a * xp[n]) / b;
+                lp[n] -= 0.5 * z * z;
+                const double gfull = gprev[n] + a * z / b;
+                gd[n] += clipc(gfull, cl) * rp;
+                gprev[n] = -z / b;
+                xp[n] = xi;
+            }
+            rp = r;
+        }
+#pragma unroll
+        for (int n = 0; n < 4; n++) { o.gd[n] = gd[n] + clipc(gprev[n], cl) * rp; o.lp[n] = lp[n]; }
     } else {
         double acc[4] = {0, 0, 0, 0}, gd[4] = {0, 0, 0, 0};
         for (int i = 0; i < D; i++) {
@@ -709,13 +732,23 @@ __device__ __forceinline__ double grad_elem(const KParams &p, int i, double x, d
 // line sums of (theta_i, r_i) for coordinate i (r still unnormalised): A, B', C', max|a|, max|r| (a, r scaled by 1/s_i for
 // ill-normal; the maxima by 1/s_i^2, since |g_i| = |x_i| / s_i^2); the funnel's coordinate 0 (v) is kept aside
 template <int MODEL>
-__device__ __forceinline__ void line_accumulate(const KParams &p, int i, double th, double r, LineStat &st, double &Bs, double &Cs, double &m1) {
+__device__ __forceinline__ void line_accumulate(const KParams &p, int i, double th, double r, LineStat &st, double &Bs, double &Cs, double &m1,
+                                                double &pth, double &pr) {
     double a = th, rs = r;
     if constexpr (MODEL == MODEL_ILL_NORMAL) { const double is = p.md.aux[i]; a = a * is; rs = rs * is; }
+    if constexpr (MODEL == MODEL_AR1) {
+        // ar1 (stan/ar1.stan): log p = -0.5 x_0^2 - 0.5 sum_i z_i^2, z_i = (x_i - 0.9 x_{i-1}) / b — on a line z_i is linear in t, so the
+        // sums run over (u_i, w_i) = the z-transforms of theta and of the direction (i = 0: the coordinate itself)
+        const double ca = 0.9, cb = sqrt(1 - ca * ca);
+        if (i > 0) { a = (th - ca * pth) / cb; rs = (r - ca * pr) / cb; }
+        pth = th; pr = r;
+    }
     if (MODEL == MODEL_FUNNEL && i == 0) { st.v0 = a; st.r0 = r; }
     else {
         st.A = fma(a, a, st.A); Bs = fma(a, rs, Bs); Cs = fma(rs, rs, Cs);
         if constexpr (MODEL == MODEL_ILL_NORMAL) { const double is = p.md.aux[i]; a = a * is; rs = rs * is; }
+        // ar1: |g_i| = |-z_i + 0.9 z_{i+1}| / b  (|g_0| <= |x_0| + 0.9 |z_1| / b)  <=  (1.9 / b) max_j |z_j|
+        if constexpr (MODEL == MODEL_AR1) { const double kap = 1.9 / sqrt(1 - 0.81); a = a * kap; rs = rs * kap; }
         st.m0 = fmax(st.m0, fabs(a)); m1 = fmax(m1, fabs(rs));
         if (a != a || rs != rs) st.m0 = NAN;
     }
@@ -967,6 +1000,7 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
         double nn = 1.0;
         LineStat st = {0, 0, 0, 0, 0, 0, 0};
         double Bs = 0, Cs = 0, m1 = 0;       // direction sums, still on the unnormalised r
+        double prev_th = 0, prev_r = 0;      // (ar1: the previous coordinate)
         if (p.phases & PH_DIR) {
             if (role == 2) draw_normals();
             KLHR_STAMP(st_norm);
@@ -1021,7 +1055,7 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
                         const double r = m + sqrt(b.cv[k]) * Zn[b.rk[k] * W];
                         n2 += (r + p.tol) * (r + p.tol);
                         rho[i * W] = r;
-                        line_accumulate<MODEL>(p, i, b.th[k], r, st, Bs, Cs, m1);
+                        line_accumulate<MODEL>(p, i, b.th[k], r, st, Bs, Cs, m1, prev_th, prev_r);
                     }
                 });
             nn = sqrt(n2);
@@ -1033,7 +1067,7 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
 #pragma unroll
                 for (int k = 0; k < N; k++) { rr[k] = rho[(i0 + k) * W]; th[k] = theta[(i0 + k) * W]; }
 #pragma unroll
-                for (int k = 0; k < N; k++) line_accumulate<MODEL>(p, i0 + k, th[k], rr[k], st, Bs, Cs, m1);
+                for (int k = 0; k < N; k++) line_accumulate<MODEL>(p, i0 + k, th[k], rr[k], st, Bs, Cs, m1, prev_th, prev_r);
             });
         }
         {

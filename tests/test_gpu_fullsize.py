@@ -81,12 +81,13 @@ def test_odd_chain_counts_every_variant(name):
                     assert np.array_equal(th[0], first), (name, variant, over, C)
 
 
-def test_mapping_thresholds_do_not_show_in_a_chain():
+@pytest.mark.parametrize("name", ["funnel100", "ar1x100"])
+def test_mapping_thresholds_do_not_show_in_a_chain(name):
     """The split pipeline switches mappings with the chain count: 16-chain tiles with paired streaming wavefronts up to 16 384
     chains, 64-chain tiles above; the node-parallel fit kernel up to 32 768 chains, the lane = chain fit kernels above.
     The first chains' states after 60 draws (first window closure included) are the same bits on both sides of each threshold
     and in a small launch."""
-    stem, data = model_spec("funnel100")
+    stem, data = model_spec(name)
     n, base = 60, 31000
     ref = None
     for C in (40, 16384, 16385, 32768, 32769):

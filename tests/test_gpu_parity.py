@@ -115,10 +115,10 @@ G8 = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "g8_*_w*
 
 
 def ill_conditioned(oracle, R, m, init):
-    """How far the ORACLE's own KL fit of record m moves (relative, max over eta) when init[2] changes by one ulp: the
-    conditioning of that record's optimisation problem.  ~1e-14 for an ordinary record, > 1e-4 for the rare fit that walks
-    dozens of evaluations along a flat valley — there no two implementations (not SciPy's own two algebraically equal
-    forms of the BFGS update either) end at the same point."""
+    """How far the ORACLE's own KL fit of record m moves (relative, max over eta) when one component of init changes by one
+    ulp (each of the four, either way; the largest movement counts): the conditioning of that record's optimisation problem.
+    ~1e-14 for an ordinary record, > 1e-4 for the rare fit that walks dozens of evaluations along a flat valley — there no
+    two implementations (not SciPy's own two algebraically equal forms of the BFGS update either) end at the same point."""
     import ctypes as C
     L = oracle.lib()
     dp = C.POINTER(C.c_double)
@@ -126,15 +126,18 @@ def ill_conditioned(oracle, R, m, init):
     c = oracle.Chain(R["stem"], R["data"], seed=0, warmup=R["warmup"], **R["flags"])
     c.set("theta", R["g"]["theta_before"][m])
     rho = np.ascontiguousarray(R["g"]["rho"][m])
-    outs = []
-    for nudge in (0, 1):
-        x0 = np.array(init, dtype=np.float64)
-        if nudge:
-            x0[2] = np.nextafter(x0[2], 10.0)
+    def run(x0):
         out = np.zeros(10)
         L.klhr_oracle_bfgs(c._h, rho.ctypes.data_as(dp), 4, x0.ctypes.data_as(dp), 1e-3, out.ctypes.data_as(dp))
-        outs.append(out[:4].copy())
-    return float(np.max(np.abs(outs[0] - outs[1]) / (1.0 + np.abs(outs[0]))))
+        return out[:4].copy()
+    base = run(np.array(init, dtype=np.float64))
+    worst = 0.0
+    for k in range(4):
+        for towards in (10.0, -10.0):
+            x0 = np.array(init, dtype=np.float64)
+            x0[k] = np.nextafter(x0[k], towards)
+            worst = max(worst, float(np.max(np.abs(run(x0) - base) / (1.0 + np.abs(base)))))
+    return worst
 
 
 @pytest.mark.parametrize("fn", G8)
@@ -189,7 +192,7 @@ def test_teacher_forced_pieces_vs_oracle(oracle, fn):
     # round 2, lane / octet / split kernels alike: worst record 1e-11 on funnel / normal / ill-normal / funnel-100,
     # 9e-11 on ar1, 3e-9 on glmm-poisson, 2e-7 on earnings whose +-300 clip leaves fits at rounding-noise level), with one
     # decade of margin.  A record may exceed it only if the ORACLE ITSELF is that sensitive there: its own minimiser moves
-    # by more than 1e-7 when init[2] is changed by one ulp (ill_conditioned below).  g8_funnel10_s7_w1000 holds one such
+    # by more than 1e-7 when a component of init is changed by one ulp (ill_conditioned below).  g8_funnel10_s7_w1000 holds one such
     # record (#137: a 34-40 evaluation walk along a flat valley of KL; the oracle lands 2.3e-3 away after a one-ulp nudge,
     # SciPy-literal and rank-two forms of the same BFGS update 1.0e-3 apart, the reference itself 8e-4 from the oracle).
     tol_eta = {"earnings": 2e-6, "glmm-poisson": 1e-7}.get(R["stem"], 1e-9)
@@ -201,7 +204,7 @@ def test_teacher_forced_pieces_vs_oracle(oracle, fn):
         init = [o_rec["init0"], o_rec["init1"], o_rec["init2"], o_rec["init3"]]
         moved = ill_conditioned(oracle, R, m, init)
         print(f"{fn}: record {m}: eta differs by {worst_o[np.flatnonzero(sel) == m][0]:.2e} at equal evaluation counts; "
-              f"the oracle's own minimiser moves by {moved:.2e} under a one-ulp change of init[2]")
+              f"the oracle's own minimiser moves by {moved:.2e} under a one-ulp change of one component of init")
         assert moved > 1e-7, (fn, m, moved)
         # ... and both fits reached the same objective value to the level gtol = 1e-3 implies
         assert abs(d[m, col["fun2"]] - o_rec["fun2"]) <= 1e-5 * (1.0 + abs(o_rec["fun2"])), (fn, m)
@@ -702,7 +705,7 @@ def test_asynchronous_chains_equal_synchronous_rounds(monkeypatch, kernel_mode):
         assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("name", ["funnel100", "illnormal100", "funnel10"])
+@pytest.mark.parametrize("name", ["funnel100", "illnormal100", "funnel10", "ar1x100"])
 @pytest.mark.parametrize("variant,over", [(0, False), (0, True), (1, False), (2, False)])
 def test_node_parallel_fit_equals_lane_per_chain_fit(monkeypatch, kernel_mode, name, variant, over):
     """Split pipeline: up to 32 768 chains both stages of fit() run in klhr_fitn_kernel (8 lanes per chain, one quadrature
@@ -753,7 +756,7 @@ def test_handed_over_fits_equal_fits_finished_in_place(monkeypatch, kernel_mode,
             assert np.array_equal(a, b, equal_nan=True)
 
 
-@pytest.mark.parametrize("name", ["funnel100", "illnormal100"])
+@pytest.mark.parametrize("name", ["funnel100", "illnormal100", "ar1x100"])
 @pytest.mark.parametrize("variant,over,flags", [(0, False, {}), (0, True, {}), (1, False, {}), (2, False, {}),
                                                 (0, False, {"scale_dir_cov": True}), (0, False, {"eigen_method_one": True})])
 def test_paired_streaming_wavefronts_equal_single_wavefront(monkeypatch, kernel_mode, name, variant, over, flags):
@@ -763,6 +766,8 @@ def test_paired_streaming_wavefronts_equal_single_wavefront(monkeypatch, kernel_
     chain counts that leave the last tile / workgroup partly empty."""
     if kernel_mode != "split":
         pytest.skip("the streaming kernel of the split pipeline")
+    if name == "ar1x100" and flags.get("scale_dir_cov"):
+        pytest.skip("ar1 with scale_dir_cov runs on the octet kernel")
     stem, data = model_spec(name)
     for C in (203, 16, 33):
         seeds = np.arange(C, dtype=np.uint64) + 5200
@@ -811,7 +816,7 @@ def test_whole_iterations_per_tile_equal_the_kernel_sequence(monkeypatch, kernel
             assert np.array_equal(a, b, equal_nan=True)
 
 
-@pytest.mark.parametrize("name", ["funnel100", "illnormal100"])
+@pytest.mark.parametrize("name", ["funnel100", "illnormal100", "ar1x100"])
 def test_fit_kernel_forms_agree_over_a_population(monkeypatch, kernel_mode, name):
     """2 048 chains x 30 draws through the lane = chain fit kernels, the node-parallel fit kernel and the whole-iterations-per-tile
     kernel: the same bits.  (With the optimiser compiled under -ffp-contract=fast the back end fused a multiplication and an
