@@ -90,8 +90,8 @@ KLHR_API int klhr_dim(const klhr_sampler *s);                  /* replaces BSMod
 KLHR_API int klhr_chains(const klhr_sampler *s);
 KLHR_API int klhr_sync(klhr_sampler *s);                       /* wait for the handle's stream */
 /* which hot-path kernels this handle launches: 0 = octet-per-chain (klhr_iter_kernel), 1 = lane-per-chain
- * (klhr_lane_kernel, model dimension <= 26), 2 = split-phase pipeline (streaming kernel + klhr_fit1_kernel +
- * klhr_fit2_kernel: funnel / ill-normal / normal / ar1 above dimension 26), 3 = split-phase pipeline with both fit stages in
+ * (klhr_lane_kernel, model dimension <= 26), 2 = split-phase pipeline (streaming kernel + klhr_fit12_kernel, i.e. both fit stages lane = chain;
+ * klhr_fit1_kernel / klhr_fit2_kernel in the asynchronous and hand-over modes: funnel / ill-normal / normal / ar1 above dimension 26), 3 = split-phase pipeline with both fit stages in
  * the node-parallel klhr_fitn_kernel (up to 32 768 chains), 4 = as 2 with long KL fits handed to klhr_fit2r_kernel
  * (KLHR_FIT_RESUME=1), 5 = as 3, and klhr_step runs whole iterations per 16-chain tile in one launch (klhr_tile_kernel,
  * up to 8 192 chains; the pieces of the C ABI and diagnostic steps use the kernels of 3).  Results agree within the stated tolerances (2, 3, 4, 5: bit for bit); only the mapping to the machine

@@ -218,7 +218,7 @@ class Sampler:
     def kernel_names(self):
         """the hot-path kernels of this handle by name, in the slot order of kernel_times()"""
         stream = "klhr_stream16_kernel" if self._L.klhr_tile_width(self._h) == 16 else "klhr_stream_kernel"
-        return {0: ["klhr_iter_kernel"], 1: ["klhr_lane_kernel"], 2: [stream, "klhr_fit1_kernel", "klhr_fit2_kernel"],
+        return {0: ["klhr_iter_kernel"], 1: ["klhr_lane_kernel"], 2: [stream, "(none)", "klhr_fit12_kernel"],
                 3: [stream, "(none)", "klhr_fitn_kernel"],
                 4: [stream, "klhr_fit1_kernel", "klhr_fit2_kernel+klhr_fit2r_kernel"],
                 5: ["klhr_tile_kernel"]}[self._L.klhr_kernel_variant(self._h)]

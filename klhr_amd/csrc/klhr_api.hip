@@ -696,10 +696,11 @@ static int run_phases(klhr_sampler *s, int phases, int64_t n_iters, int record_d
                 if (do_tail || do_head) launch_split(s, kp, 0, do_tail, do_head, st);
                 if (mark((int)it * 4 + 1)) return KLHR_ERR_HIP;
                 if (it < n_iters && (phases & PH_FIT)) {
-                    if (!s->fitn) launch_split(s, kp, 1, 0, 0, st);
+                    const bool two_launches = !s->fitn && kp.resume_budget;        // (the hand-over list is zeroed by the mode-search kernel)
+                    if (two_launches) launch_split(s, kp, 1, 0, 0, st);
                     if (mark((int)it * 4 + 2)) return KLHR_ERR_HIP;
-                    launch_split(s, kp, s->fitn ? 4 : 2, 0, 0, st);
-                    if (!s->fitn && kp.resume_budget) launch_split(s, kp, 5, 0, 0, st);
+                    launch_split(s, kp, s->fitn ? 4 : (two_launches ? 2 : 8), 0, 0, st);
+                    if (two_launches) launch_split(s, kp, 5, 0, 0, st);
                     if (mark((int)it * 4 + 3)) return KLHR_ERR_HIP;
                 }
                 if (it < n_iters && (phases & (PH_KL | PH_LINE))) {
@@ -801,7 +802,7 @@ extern "C" int klhr_last_kernel_times(klhr_sampler *s, double ms3[3], int n3[3])
             HIPCHECK(s, hipEventElapsedTime(&ms, s->pev[it * 4 + k], s->pev[it * 4 + k + 1]));
             tot[k] += ms; n3[k] += 1;
         }
-    if (s->fitn) { tot[1] = 0; n3[1] = 0; }          // (the node-parallel kernel runs both stages: slot 2)
+    if (s->fitn || !s->resume) { tot[1] = 0; n3[1] = 0; }          // (one kernel runs both stages: slot 2)
     for (int k = 0; k < 3; k++) ms3[k] = n3[k] ? tot[k] / n3[k] : 0;
     return KLHR_OK;
 }

@@ -34,6 +34,8 @@ static void launch_split_model(const KParams &kp0, int what, bool overrelaxed, i
         hipLaunchKernelGGL((klhr_fit1_kernel<MODEL>), dim3(fitgrid), block, 0, stream, kp);
     } else if (what == 2) {
         hipLaunchKernelGGL((klhr_fit2_kernel<MODEL, V>), dim3(fitgrid), block, 0, stream, kp);
+    } else if (what == 8) {
+        hipLaunchKernelGGL((klhr_fit12_kernel<MODEL, V>), dim3(fitgrid), block, 0, stream, kp);
     } else if (what == 7) {
         // whole iterations per tile (klhr_tile_kernel): one workgroup of two wavefronts per 16-chain tile, kp.n_iters draws
         kp.stream_pair = 1; kp.stream_waves = 2;
@@ -67,7 +69,8 @@ static void launch_split_model(const KParams &kp0, int what, bool overrelaxed, i
 }
 
 // what: 0 streaming kernel (do_tail / do_head), 1 mode search, 2 KL fit, 3 KL / line probe, 4 both fit stages node-parallel,
-// 5 node-parallel resume of the KL fits klhr_fit2_kernel handed over, 7 whole iterations per tile (kp.n_iters draws in one launch)
+// 5 node-parallel resume of the KL fits klhr_fit2_kernel handed over, 7 whole iterations per tile (kp.n_iters draws in one launch),
+// 8 both fit stages lane = chain in one launch
 void KLHR_CAT2(launch_split_v, KLHR_VARIANT)(const KParams &kp, int model_id, int what, bool overrelaxed, int do_tail, int do_head, hipStream_t stream) {
     switch (model_id) {
     case KLHR_MODEL_FUNNEL: launch_split_model<MODEL_FUNNEL>(kp, what, overrelaxed, do_tail, do_head, stream); break;

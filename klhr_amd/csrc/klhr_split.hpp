@@ -203,7 +203,7 @@ __device__ __forceinline__ void opt_restore(const KParams &p, long long c, Opt &
 
 // Stage 1 of fit(): minimize(logp_grad_rho, x0, BFGS, gtol = 1e-5) (klhr_sinh.py:183-190)
 template <int MODEL>
-__global__ __launch_bounds__(64) void klhr_fit1_kernel(const KParams p) {
+__device__ __forceinline__ void fit1_body(const KParams &p) {
     const int lane = threadIdx.x & 63;
     if (p.resume_budget && blockIdx.x == 0 && threadIdx.x == 0) *p.resume_count = 0;      // (the KL fit of this round fills the list)
     const long long task = (long long)blockIdx.x * p.fit_lanes + lane;
@@ -262,9 +262,12 @@ __global__ __launch_bounds__(64) void klhr_fit1_kernel(const KParams p) {
     if (p.async_mode) p.phase[task] = ph;
 }
 
+template <int MODEL>
+__global__ __launch_bounds__(64) void klhr_fit1_kernel(const KParams p) { fit1_body<MODEL>(p); }
+
 // Stage 2 of fit(): minimize(KL, init, BFGS, gtol = 1e-3) (klhr_sinh.py:191-201; klhr.py:134-139; sub_klhr_sinh.py:184-192)
 template <int MODEL, int VARIANT>
-__global__ __launch_bounds__(64) void klhr_fit2_kernel(const KParams p) {
+__device__ __forceinline__ void fit2_body(const KParams &p) {
     constexpr int N = VARIANT == VAR_GAUSS ? 2 : (VARIANT == VAR_SUB ? 3 : 4);
     const int lane = threadIdx.x & 63;
     const long long task = (long long)blockIdx.x * p.fit_lanes + lane;
@@ -331,6 +334,15 @@ __global__ __launch_bounds__(64) void klhr_fit2_kernel(const KParams p) {
         }
     }
     if (p.async_mode) p.phase[task] = ph;
+}
+template <int MODEL, int VARIANT>
+__global__ __launch_bounds__(64) void klhr_fit2_kernel(const KParams p) { fit2_body<MODEL, VARIANT>(p); }
+// Both stages, lane = chain, in one launch (the synchronous rounds with many chains): one launch and one launch tail less per
+// iteration; a lane's stage 2 reads back what its stage 1 wrote.  The bodies are the two kernels' own.
+template <int MODEL, int VARIANT>
+__global__ __launch_bounds__(64) void klhr_fit12_kernel(const KParams p) {
+    fit1_body<MODEL>(p);
+    fit2_body<MODEL, VARIANT>(p);
 }
 
 // ------------------------------------------------------------------------------------------------
