@@ -686,6 +686,89 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
             bool done = false;
             int trips = 0;
             dg_pass = 0;
+#ifndef KLHR_OCTET_ONE_LOOP
+            // Two loops, as in the lane kernel: every octet of the wavefront finishes its mode search (cheap passes: the line
+            // objective over the octet, opt_advance<1>) before the KL fits start (opt_advance<N>).  In one mixed loop a pass costs
+            // a full KL evaluation as soon as one octet is in stage 2, so the wavefront paid max(n1 + n2) full passes; now
+            // max(n1) cheap ones + max(n2), and the octets of a pass are all in the same stage of the optimiser.
+            // Values are those of the mixed loop (the dimension-specialised opt_advance adds the same numbers without the zeros).
+            constexpr int NFIT = VARIANT == VAR_GAUSS ? 2 : (VARIANT == VAR_SUB ? 3 : 4);
+            bool done1 = false;
+            for (;;) {
+                double f = 0, g[4] = {0, 0, 0, 0};
+                KLHR_STAMP(st_idle);
+#ifdef KLHR_STAMPS
+                st_npass++;
+#endif
+                if (!done1) {
+                    if (opt_cache_hit(o)) { f = o.lf; g[0] = o.lg[0]; }
+                    else {
+                        eval_objective<MODEL, VARIANT>(p, md, TR, 1, o.xt, asx_l, w_l, l8, f, g);
+                        opt_cache_store(o, f, g);
+                        dg_pass++;
+                    }
+                    KLHR_STAMP(st_eval);
+                    opt_advance<false, 1>(o, f, g);
+                    if (o.pc == PC_DONE) done1 = true;
+                    KLHR_STAMP(st_adv);
+                }
+                if (__all(done1) || ++trips > KLHR_MAX_PASSES) break;
+            }
+            if (done1) {
+                gevals += o.nfev;
+                dg_mode = o.xk[0]; dg_hinv1 = o.H[0]; dg_nfev1 = o.nfev; dg_nit1 = o.k; dg_st1 = o.status; dg_fb = o.fallbacks;
+                double s = o.H[0];
+                s = (s > 0 ? 1.0 : 0.0) * 0.5 * log(s);
+                if (VARIANT == VAR_GAUSS) {          // klhr.py:134-139: no extra normals, default gtol
+                    double init[4] = {o.xk[0], s, 0.0, 0.0};
+                    for (int k = 0; k < 4; k++) dg_init[k] = init[k];
+                    opt_begin(o, 2, init, 1e-5);
+                } else {
+                    // init = rng.normal(size=4) * initscale, then [0], [1] overwritten (klhr_sinh.py:191-193):
+                    // four normals are consumed, the first two discarded; SUBKLHRSINH draws size=3 (sub_klhr_sinh.py:184)
+                    (void)rng_std_normal(rng);
+                    (void)rng_std_normal(rng);
+                    const double n2 = rng_std_normal(rng) * p.initscale;
+                    const double n3 = VARIANT == VAR_SUB ? 0.0 : rng_std_normal(rng) * p.initscale;
+                    double init[4] = {o.xk[0], s, n2, n3};
+                    for (int k = 0; k < 4; k++) dg_init[k] = init[k];
+                    opt_begin(o, VARIANT == VAR_SUB ? 3 : 4, init, 1e-3);
+                }
+            }
+            done = !done1;          // (a capped mode search: no KL fit; `done` is cleared again below)
+            for (;;) {
+                double f = 0, g[4] = {0, 0, 0, 0};
+                KLHR_STAMP(st_idle);
+#ifdef KLHR_STAMPS
+                st_npass++;
+#endif
+                if (!done) {
+                    if (opt_cache_hit(o)) {
+                        f = o.lf; g[0] = o.lg[0]; g[1] = o.lg[1]; g[2] = o.lg[2]; g[3] = o.lg[3];
+                    } else {
+                        eval_objective<MODEL, VARIANT>(p, md, TR, NFIT, o.xt, asx_l, w_l, l8, f, g);
+                        opt_cache_store(o, f, g);
+                        dg_pass++;
+                    }
+#ifdef KLHR_FIT_PRINTF
+                    if (c == 0 && l8 == 0)
+                        printf("pass %d pc %d x %.17g %.17g %.17g %.17g f %.17g g %.17g %.17g %.17g %.17g oldf %.17g\n", dg_pass, (int)o.pc,
+                               o.xt[0], o.xt[1], o.xt[2], o.xt[3], f, g[0], g[1], g[2], g[3], o.old_fval);
+#endif
+                    KLHR_STAMP(st_eval);
+                    opt_advance<false, NFIT>(o, f, g);
+                    if (o.pc == PC_DONE) {
+                        gevals += (long long)o.nfev * 8;
+                        for (int k = 0; k < 4; k++) eta[k] = o.xk[k];
+                        dg_nfev2 = o.nfev; dg_nit2 = o.k; dg_st2 = o.status; dg_fun2 = o.old_fval; dg_fb += o.fallbacks;
+                        done = true;
+                    }
+                    KLHR_STAMP(st_adv);
+                }
+                if (__all(done) || ++trips > KLHR_MAX_PASSES) break;
+            }
+            if (!done1) done = false;
+#else
             for (;;) {
                 double f = 0, g[4] = {0, 0, 0, 0};
                 KLHR_STAMP(st_idle);
@@ -744,6 +827,7 @@ __global__ __launch_bounds__(64) void klhr_iter_kernel(const KParams p)
                 }
                 if (__all(done) || ++trips > KLHR_MAX_PASSES) break;
             }
+#endif
             if (!done) { fit_capped = true; for (int k = 0; k < 4; k++) eta[k] = o.xk[k]; }
             if (p.flags & FLAG_DIAG) {
                 const double e_sel = l8 == 0 ? eta[0] : (l8 == 1 ? eta[1] : (l8 == 2 ? eta[2] : eta[3]));
