@@ -1,0 +1,44 @@
+"""Regenerate the round-2 section of profiles/README.md from the CSV summaries under profiles/r02_*: python tools/profiles_readme.py"""
+import csv, collections, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.chdir(ROOT)
+def sq(tag):
+    agg = collections.defaultdict(dict); meta = {}
+    for r in csv.DictReader(open(f"profiles/{tag}/pmc_sq.csv")):
+        agg[r["kernel"]][r["counter"]] = float(r["mean_per_dispatch"]); meta[r["kernel"]] = (r["vgpr"], r["agpr"], r["scratch"])
+    out = []
+    for k, m in agg.items():
+        w = m["SQ_WAVES"]; wc = m["SQ_WAVE_CYCLES"] * 4
+        out.append((k.replace("void klhr::", ""), f"{m['SQ_ACTIVE_INST_VALU']*4/wc*100:.0f} %", f"{m['SQ_WAIT_ANY']*4/wc*100:.0f} %",
+                    f"{m['SQ_THREAD_CYCLES_VALU']/(m['SQ_ACTIVE_INST_VALU']*64)*100:.0f} %", f"{wc/m['SQ_INSTS_VALU']:.1f}", f"{m['SQ_INSTS_VALU']/w:.3g}", "/".join(meta[k])))
+    return out
+def ks(tag):
+    rows = [r for r in csv.DictReader(open(f"profiles/{tag}/kernel_stats.csv")) if "klhr" in r["Name"] and "init" not in r["Name"]]
+    return [(r["Name"].split("(")[0].replace("void klhr::", ""), int(r["Calls"]), float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["Percentage"])) for r in rows]
+DESC = {"r02_octet_ill": "ill-normal-100 × 16 384, round-1 octet kernel (baseline of round 2)", "r02_octet_f100": "funnel-100 × 131 072, round-1 octet kernel (baseline)",
+        "r02_octet_glmm": "glmm-poisson-45 × 8 192, round-1 octet kernel (baseline)", "r02_octet_glmm_now": "glmm-poisson-45 × 8 192, staged model data read as LDS",
+        "r02_octet_glmm_final": "glmm-poisson-45 × 8 192, end of round 2 (`exp` over year blocks, two-loop fit)",
+        "r02_split_ill": "ill-normal-100 × 16 384, split pipeline, first form (one wavefront per tile, lane = chain fit kernels)",
+        "r02_split_ill_final": "ill-normal-100 × 16 384, end of round 2 (pair-mode streaming kernel, node-parallel fit)",
+        "r02_split_f100": "funnel-100 × 131 072, split pipeline, end of round 2 (both fit stages in one launch)",
+        "r02_lane_f10": "funnel-10 × 65 536 (headline), lane kernel with closed-form fits, end of round 2"}
+txt = "\n\n## Round 2 (`r02_*`): one directory per configuration and kernel mapping\n\n"
+txt += ("Commands: `tools/profile_cfg.sh <tag> <model> <dim> <chains> [steps]` on the GPU box (kernel-trace `--stats`, two SQ counter passes, `--pmc FETCH_SIZE`, "
+        "`--pmc WRITE_SIZE`, each its own run of `bench.py --model … --no-configs`; the split pipeline with `KLHR_GROUPS=1` so that kernels do not overlap), summaries copied by "
+        "`tools/profile_cfg_collect.py`, which also writes `traffic.json[<model>-<dim>-<chains>]` (what `bench.py` reports as `roofline.traffic`; FETCH_SIZE ÷ 0.5 for the tiled reads "
+        "of the split pipeline, ÷ 1.383 for the lane-private rows of the monolithic kernels: `r02_calibration/rowcal.csv`).  Each directory: `kernel_stats.csv` (rocprofv3 `--stats`), "
+        "`pmc_sq.csv` (mean per dispatch over the last third of the dispatches), `pmc_fetch_write.csv`.  The average durations include the 150 untimed setup draws (window closures, first "
+        "launches); `bench.py`'s `roofline.kernels` are HIP-event means over 20 post-setup iterations and sit between the minimum and the average here.  (This section is generated: "
+        "`tools/profiles_readme.py`.)\n\n")
+txt += "| dir | configuration, build | kernels: calls, average / minimum duration (µs), share |\n|---|---|---|\n"
+for tag, d in DESC.items():
+    txt += f"| `{tag}/` | {d} | " + "; ".join(f"`{n}` ×{c}: {a:.1f} / {m:.1f}, {p:.1f} %" for n, c, a, m, p in ks(tag)) + " |\n"
+txt += ("\nSQ counters (per kernel: VALU-active share of the wave cycles, share waiting in `s_waitcnt`, lanes active on issued VALU instructions, cycles per VALU instruction, VALU "
+        "instructions per wavefront and dispatch, VGPR/AGPR/scratch as rocprofv3 reports them):\n\n| dir | kernel | VALU-active | waiting | lanes active | cycles / VALU | VALU / wavefront | VGPR/AGPR/scratch |\n|---|---|---|---|---|---|---|---|\n")
+for tag in DESC:
+    for row in sq(tag):
+        txt += f"| `{tag}/` | `{row[0]}` | {row[1]} | {row[2]} | {row[3]} | {row[4]} | {row[5]} | {row[6]} |\n"
+s = open("profiles/README.md").read()
+i = s.index("\n\n## Round 2 (`r02_*`)"); j = s.index("\n`r02_stamps/`")
+open("profiles/README.md", "w").write(s[:i] + txt + s[j:])
+print("profiles/README.md regenerated")
