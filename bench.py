@@ -15,8 +15,11 @@ adaptation windows have closed (experiment_funnel.py:21 default) — plus 50 mor
 REPEATS (5) regions of exactly K steps, each bracketed by barrier + device sync on both sides, max over ranks; the
 MEDIAN region gives `ms_per_step` and `value`, min / max are reported beside it.  Inputs (chain state) are resident in HBM
 when a timed region starts; draws are recorded into an HBM buffer inside it and never copied to the host there.
-ESS/sec comes from a separate, fixed post-warm-up run (2 048 chains x 1 000 draws, outside the timed regions): ESS per
-chain-iteration x the measured iterations/sec.  Rank 0 prints ONE JSON line.
+ESS/sec comes from a separate, fixed run outside the timed regions (512 chains: setup, 3 000 burn-in draws, 20 000 recorded
+draws): ESS per chain-iteration x the measured iterations/sec, reported only when Geyer's truncation lag is below a tenth of
+the run (otherwise null + reason).  With N > 1 ranks every rank also runs BASELINE config 5's per-GPU shard (funnel-100D,
+131 072 chains) with pooled="full" adaptation — the RCCL all-reduce inside the library — and rank 0 reports it under
+`configs` and `rccl`; the headline stays parity mode (no collective).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -93,11 +96,21 @@ def cpu_baseline(chains, warm, iters, threads):
 
 
 def traffic_entry(key):
+    """profiles/traffic.json[key] if it was measured on the library build that is loaded (klhr_build_id == the entry's
+    build_id), else (None, reason): counters of a kernel that has changed since are not quoted."""
+    from klhr_amd import _lib
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     try:
-        return json.load(open(tpath)).get(key)
-    except Exception:
-        return None
+        te = json.load(open(tpath)).get(key)
+    except Exception as e:
+        return None, f"profiles/traffic.json unreadable: {e}"
+    if te is None:
+        return None, f"no entry {key!r} in profiles/traffic.json"
+    have = _lib.build_id()
+    if te.get("build_id") != have:
+        return None, (f"profiles/traffic.json[{key!r}] was measured on build {str(te.get('build_id'))[:16]}, the loaded library is "
+                      f"{have[:16]}: re-run tools/profile_cfg.sh + tools/profile_cfg_collect.py")
+    return te, None
 
 
 def run_workload(model, dim, C, steps, warm, repeats, rank, world, device, seed, dist, pooled=None, profile_iters=20):
@@ -115,13 +128,19 @@ def run_workload(model, dim, C, steps, warm, repeats, rank, world, device, seed,
     comm = None
     if pooled:
         from klhr_amd.parallel import pooled_setup_draws
-        comm = pooled_setup_draws(s, SETUP_DRAWS, rank, world, dist, mode=pooled)
+
+        def host_sum(vec):          # stand-in for rehearsals whose ranks share one GPU (RCCL needs one device per rank)
+            import torch
+            t = torch.from_numpy(np.array(vec, dtype=np.float64))
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return t.numpy()
+        comm = pooled_setup_draws(s, SETUP_DRAWS, rank, world, dist, mode=pooled, host_allreduce=host_sum if dist is not None else None)
     else:
         s.step(SETUP_DRAWS)                 # the sampler's own adaptation: untimed setup, whatever --warmup says
     if warm > 0:
         s.step(warm)
     s.reserve_draws(steps)                  # the output buffer (np.zeros((M, D)) in experiment_funnel.py:48) exists before the clock starts
-    region = []
+    region, region_kernel = [], []
     for _ in range(repeats):
         s.sync()
         barrier()
@@ -131,6 +150,7 @@ def run_workload(model, dim, C, steps, warm, repeats, rank, world, device, seed,
         s.sync()
         barrier()
         dt = time.perf_counter() - t0
+        region_kernel.append(s.timing())     # HIP events around this region's launches on the handle's stream: (ms, launches)
         if dist is not None:
             import torch
             t = torch.tensor([dt], dtype=torch.float64)
@@ -140,50 +160,75 @@ def run_workload(model, dim, C, steps, warm, repeats, rank, world, device, seed,
     dt_med = float(np.median(region))
     total_iters = world * C * steps
     value = total_iters / dt_med
-    # ---- per-kernel durations from HIP events on the launch stream (untimed pass; split pipeline: one chain group)
-    s.kernel_profiling(True)
-    # (monolithic kernels run the whole call in one or a few launches: profile a call of the timed length, so that every
-    #  dispatch a rocprofv3 pass sees at the end of the run covers the same number of iterations)
-    n_prof = min(steps, profile_iters) if len(s.kernel_names()) > 1 else steps
-    s.step(n_prof, record_draws=True)
-    kms, kn = s.kernel_times()
-    s.kernel_profiling(False)
     names = s.kernel_names()
+    mono = len(names) == 1
     b_iter = algorithmic_bytes_per_iter(D)
+    kernels = {}
+    if mono:
+        # one hot kernel: its launch duration comes from the TIMED regions' own HIP events (median region), so the kernel time
+        # per step can never exceed ms_per_step
+        kms = sorted(ms / max(nl, 1) for ms, nl in region_kernel)[len(region_kernel) // 2]
+        nl = region_kernel[0][1]
+        kernels[names[0]] = {"mean_ms": kms, "launches": nl * repeats}
+        iters_per_launch = steps / max(nl, 1)
+        times_from = "HIP events around the timed regions' launches (median region)"
+    else:
+        # split pipeline: the timed regions run 2-4 chain groups on separate streams (kernels of different groups overlap), so
+        # per-kernel durations come from a separate pass with ONE group, every kernel bracketed by HIP events on its stream
+        s.kernel_profiling(True)
+        n_prof = min(steps, profile_iters)
+        s.step(n_prof, record_draws=True)
+        kms3, kn3 = s.kernel_times()
+        s.kernel_profiling(False)
+        for nm, ms, n in zip(names, kms3, kn3):
+            if n:
+                kernels[nm] = {"mean_ms": ms, "launches": n}
+        iters_per_launch = 1.0
+        times_from = f"separate untimed pass of {n_prof} draws with one chain group (the timed regions overlap the groups' kernels)"
     ge = s.get("grad_evals").astype(np.float64)
     cnt = s.get("counters")[:, 0].astype(np.float64)
     grad_evals = float((ge / np.maximum(cnt, 1)).mean())
-    kernels = {}
-    for nm, ms, n in zip(names, kms, kn):
-        if n:
-            kernels[nm] = {"mean_ms": ms, "launches": n}
     # the roofline's kernel: the one that moves the iteration's algorithmic bytes — the hot kernel of the monolithic mappings, the
-    # streaming kernel of the split pipeline (its fit kernels work on a few doubles per chain; when they take as long as the
-    # streaming kernel, which of the two is "dominant" by time flips from run to run: `longest` says which one it was)
+    # streaming kernel of the split pipeline (its fit kernels work on a few doubles per chain; `longest_kernel` says which one
+    # took longest, `whole_iteration` is the figure over all kernels of an iteration)
     longest = max(kernels, key=lambda k: kernels[k]["mean_ms"] * kernels[k]["launches"])
     dom = names[0] if names[0] in kernels else longest
-    # iterations covered by one launch of the dominant kernel: the monolithic kernels run several per launch
-    iters_per_launch = (n_prof / kernels[dom]["launches"]) if len(names) == 1 else 1.0
     launch_s = kernels[dom]["mean_ms"] / 1e3
     achieved_gbs = b_iter * C * iters_per_launch / launch_s / 1e9
     tkey = f"{model}-{D}-{C}"
-    te = traffic_entry(tkey)
+    te, stale = traffic_entry(tkey)
     traffic = te["hbm_bytes_per_launch"] * (iters_per_launch / te["iters_per_launch"]) if te else None
     fe = flop_equiv_per_iter(D, grad_evals)
+    fp64 = {"algorithmic": {"achieved_tflops": value / world * fe / 1e12, "frac": value / world * fe / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                            "flop_equivalents_per_chain_iter": fe,
+                            "note": "SURVEY 8d's flop-equivalents of the element-wise O(D) evaluation x measured it/s; the closed-form kernels do not execute them"},
+            "peak_tflops": FP64_VALU_PEAK_TFLOPS}
+    if te and te.get("fp64_flops_per_launch"):
+        # counter-derived: (2 FMA + ADD + MUL + TRANS) fp64 instructions x 64 lanes x the lanes-active share, per launch of the
+        # dominant kernel (profiles/<tag>/pmc_sq.csv), over this run's launch duration
+        mf = te["fp64_flops_per_launch"] * (iters_per_launch / te["iters_per_launch"]) / launch_s / 1e12
+        fp64["measured"] = {"achieved_tflops": mf, "frac": mf / FP64_VALU_PEAK_TFLOPS, "source": te.get("fp64_source"),
+                            "valu_insts_per_wavefront_iteration": te.get("valu_per_wavefront_iter"), "lanes_active": te.get("lanes_active"),
+                            "valu_active": te.get("valu_active")}
+    else:
+        fp64["measured"] = None
     out = {
         "value": value, "ms_per_step": dt_med * 1e3 / steps,
         "ms_per_step_min": min(region) * 1e3 / steps, "ms_per_step_max": max(region) * 1e3 / steps, "timed_regions": repeats,
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
                      "traffic": traffic, "kernel": dom, "longest_kernel": longest, "algorithmic_bytes_per_chain_iter": b_iter,
-                     "launch_ms": launch_s * 1e3, "iters_per_launch": iters_per_launch, "kernels": kernels,
+                     "launch_ms": launch_s * 1e3, "iters_per_launch": iters_per_launch, "kernels": kernels, "kernel_times_from": times_from,
                      "whole_iteration": {"achieved": b_iter * value / world / 1e9, "frac": b_iter * value / world / 1e9 / HBM_PEAK_GBS,
                                          "note": "algorithmic bytes x measured iterations/s (all kernels of an iteration, per GPU)"},
-                     "fp64_valu": {"achieved_tflops": value / world * fe / 1e12, "peak_tflops": FP64_VALU_PEAK_TFLOPS,
-                                   "frac": value / world * fe / 1e12 / FP64_VALU_PEAK_TFLOPS, "flop_equivalents_per_chain_iter": fe}},
+                     "fp64_valu": fp64},
         "grad_evals_per_iter": grad_evals, "acceptance": float(s.get("acc").mean()), "kernel": s.kernel_name(),
     }
     if traffic is not None:
         out["roofline"]["traffic_source"] = te.get("source")
+        out["roofline"]["traffic_over_algorithmic"] = traffic / (b_iter * C * iters_per_launch)
+    else:
+        out["roofline"]["traffic_stale"] = True
+        out["roofline"]["traffic_reason"] = stale
     if comm is not None:
         out["pooled"] = comm
     s.close()
@@ -191,29 +236,53 @@ def run_workload(model, dim, C, steps, warm, repeats, rank, world, device, seed,
 
 
 def ess_run(device, seed, value):
-    """ESS of the funnel-10D chains from a fixed post-warm-up run, outside every timed region: 2 048 chains, the same setup
-    draws, then 1 000 recorded draws.  ESS/sec = ESS per chain-iteration x the headline iterations/sec (all chains)."""
+    """ESS of the funnel-10D chains from a fixed run outside every timed region: 512 chains, the same setup draws, 3 000
+    burn-in draws (the chains start at 0.1 z and need ~3 000 draws to spread over v ~ N(0, 3)), then 20 000 recorded draws.
+    ESS/sec = ESS per chain-iteration x the headline iterations/sec (all chains).  An estimate whose Geyer truncation lag
+    is not below a tenth of the run is bounded by the window rather than by the chain: reported as null with the reason."""
     from klhr_amd import _lib
-    from klhr_amd.ess import ess
-    nch, ndraw = 2048, 1000
+    from klhr_amd.ess import ess_detail
+    nch, burn, ndraw = 512, 3000, 20000
     data, D = model_data("funnel", 10)
     s = _lib.Sampler(_lib.MODEL_IDS["funnel"], data, nch, device=device, warmup=100)
     s.seed(np.uint64(seed) + np.uint64(7_000_000) + np.arange(nch, dtype=np.uint64))
     s.step(SETUP_DRAWS)
+    s.step(burn)
     s.sync()
     t0 = time.perf_counter()
     s.step(ndraw, record_draws=True)
     dt = time.perf_counter() - t0
     dr = s.draws(0, ndraw)
     s.close()
-    e_v = ess(dr[:, :, 0])
-    e_min = min(ess(dr[:, :, j]) for j in range(D))
-    per_iter_v, per_iter_min = e_v / (nch * ndraw), e_min / (nch * ndraw)
-    return {"v": per_iter_v * value, "min_coord": per_iter_min * value,
-            "ess_per_chain_iteration": {"v": per_iter_v, "min_coord": per_iter_min},
-            "estimated_on": {"chains": nch, "draws": ndraw, "after_setup_draws": SETUP_DRAWS, "its_own_it_per_s": nch * ndraw / dt},
-            "method": "rank-normalisation-free multi-chain ESS (klhr_amd/ess.py: FFT autocovariance, Geyer initial-monotone "
-                      "truncation, combined across chains), times the headline iterations/sec"}
+    det = [ess_detail(dr[:, :, j]) for j in range(D)]
+
+    def per_iter(d):
+        return d["ess"] / (nch * ndraw)
+    jmin = int(np.argmin([d["ess"] for d in det]))
+    half = [ess_detail(dr[: ndraw // 2, :, j])["ess"] / (nch * (ndraw // 2)) for j in (0, jmin)]      # stability: the same on half the run
+    ok = all(d["truncation_lag"] < ndraw / 10 for d in det)
+    out = {"v": per_iter(det[0]) * value if ok else None, "min_coord": per_iter(det[jmin]) * value if ok else None,
+           "ess_per_chain_iteration": {"v": per_iter(det[0]), "min_coord": per_iter(det[jmin]), "v_on_half_the_run": half[0],
+                                       "min_coord_on_half_the_run": half[1]},
+           "tau": {"v": det[0]["tau"], "min_coord": det[jmin]["tau"], "max_truncation_lag": max(d["truncation_lag"] for d in det),
+                   "draws_per_chain": ndraw},
+           "rhat": {"v": det[0]["rhat"], "max": max(d["rhat"] for d in det)},
+           "moments_of_v": {"mean": float(dr[:, :, 0].mean()), "sd": float(dr[:, :, 0].std()), "target": "N(0, 3)"},
+           "estimated_on": {"chains": nch, "burn_in_draws": SETUP_DRAWS + burn, "draws": ndraw, "its_own_it_per_s": nch * ndraw / dt},
+           "method": "multi-chain ESS (klhr_amd/ess.py: FFT autocovariance, within/between-chain variance, Geyer initial-monotone "
+                     "truncation), per chain-iteration, times the headline iterations/sec"}
+    if not ok:
+        out["reason"] = "Geyer truncation lag >= draws / 10 for some coordinate: the autocorrelation time is not resolved by this run"
+    return out
+
+
+def pooled_shard(rank, world, device, seed, dist):
+    """N > 1 ranks: BASELINE config 5's per-GPU shard — funnel-100D, 131 072 chains per GPU — with pooled="full" adaptation:
+    per window closure one ncclAllReduce (RCCL over xGMI) of 1 + D + D^2 doubles inside the library (klhr_comm_init /
+    klhr_pool_allreduce).  Setup draws with the pooled closures, then 3 timed regions of 50 draws.  Raises when the
+    communicator does not span all ranks (one device per rank), so that a silently skipped collective cannot pass."""
+    res, D = run_workload("funnel", 100, 131072, 50, 0, 3, rank, world, device, seed + 29, dist, pooled="full")
+    return res, D
 
 
 def main():
@@ -261,7 +330,7 @@ def main():
         "value": res["value"], "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": res["ms_per_step"], "ms_per_step_min": res["ms_per_step_min"], "ms_per_step_max": res["ms_per_step_max"],
         "timed_regions": REPEATS, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
+        "dtype": "f64", "data": "synthetic", "build_id": _lib.build_id(),
         "config": {"workload": f"{args.model}-{D}D KLHR-sinh (warmup=100, overrelaxed=False), {C} chains per GPU, draws recorded in HBM; "
                                f"timed after {SETUP_DRAWS} untimed setup draws (adaptation windows closed) + --warmup; "
                                f"median of {REPEATS} regions of --steps draws",
@@ -270,10 +339,28 @@ def main():
                                   + (f"; pooled={args.pooled} adaptation (RCCL all-reduce per window closure) during setup" if args.pooled else "")},
         "roofline": res["roofline"], "grad_evals_per_iter": res["grad_evals_per_iter"], "acceptance": res["acceptance"],
     }
-    out["roofline"]["note"] = ("the path is fp64-VALU/latency bound at D = 10, not HBM bound (DESIGN.md section 6); fp64_valu counts "
-                               "algorithmic flop-equivalents (SURVEY section 8d)")
+    out["roofline"]["note"] = ("the path is fp64-VALU/latency bound at D = 10, not HBM bound (DESIGN.md section 6); fp64_valu.algorithmic counts "
+                               "SURVEY 8d's flop-equivalents, fp64_valu.measured comes from the SQ counters of profiles/ (same build only)")
     if "pooled" in res:
         out["pooled"] = res["pooled"]
+    rccl_failed = None
+    if world > 1 and not args.no_configs:
+        # every rank takes part (the collective needs them all); rank 0 reports
+        try:
+            pr, pd = pooled_shard(rank, world, device, args.seed, dist)
+            pc = pr["pooled"]
+            rccl = {"ranks": pc["ranks"], "collective": pc["collective"], "doubles_per_allreduce": pc["doubles_per_allreduce"],
+                    "closures_pooled": pc["closures_pooled"], "allreduce_ms": pc["allreduce_plus_fetch_ms"],
+                    "comm_world": pc.get("comm_world"), "where": "untimed setup draws of the funnel-100D x 131072-per-GPU shard (BASELINE config 5)"}
+            if pc.get("one_device_per_rank") and pc.get("comm_world") != world:
+                rccl_failed = f"klhr_comm_world() = {pc.get('comm_world')} != world = {world}"
+            out["rccl"] = rccl
+            out.setdefault("configs", {})["funnel-100x131072-per-gpu-pooled-full"] = {
+                "it_per_s": pr["value"], "ms_per_step": pr["ms_per_step"], "timed_regions": 3, "steps": 50, "kernel": pr["kernel"],
+                "chains_total": 131072 * world, "pooled": "full", "roofline": {k: pr["roofline"][k] for k in ("achieved", "frac", "kernel", "launch_ms", "kernels", "whole_iteration")}}
+        except Exception as e:          # reported in the line AND through the exit code
+            rccl_failed = f"{type(e).__name__}: {e}"
+            out["rccl"] = {"error": rccl_failed}
     if rank == 0:
         if not args.no_ess:
             if headline:
@@ -289,19 +376,31 @@ def main():
                 r, dd = run_workload(m, d, c, 50, 0, 3, 0, 1, device, args.seed + 17, None)
                 cfgs[key] = {"it_per_s": r["value"], "ms_per_step": r["ms_per_step"], "ms_per_step_min": r["ms_per_step_min"],
                              "ms_per_step_max": r["ms_per_step_max"], "timed_regions": 3, "steps": 50, "kernel": r["kernel"],
-                             "roofline": {k: r["roofline"][k] for k in ("achieved", "frac", "traffic", "kernel", "launch_ms", "iters_per_launch",
-                                                                       "algorithmic_bytes_per_chain_iter", "kernels", "whole_iteration")},
-                             "fp64_valu_frac": r["roofline"]["fp64_valu"]["frac"], "grad_evals_per_iter": r["grad_evals_per_iter"],
+                             "roofline": {k: r["roofline"][k] for k in ("achieved", "frac", "traffic", "kernel", "longest_kernel", "launch_ms", "iters_per_launch",
+                                                                       "algorithmic_bytes_per_chain_iter", "kernels", "kernel_times_from", "whole_iteration",
+                                                                       "traffic_stale", "traffic_reason", "traffic_over_algorithmic") if k in r["roofline"]},
+                             "fp64_valu": r["roofline"]["fp64_valu"], "grad_evals_per_iter": r["grad_evals_per_iter"],
                              "acceptance": r["acceptance"]}
             out["configs"] = cfgs
         if world == 1 and not args.no_cpu_baseline:
-            threads = min(os.cpu_count() or 1, 16)
+            ncpu = os.cpu_count() or 1
+            try:
+                ncpu = len(os.sched_getaffinity(0))          # the cores this process may actually use (a 1-GPU box hands out a share)
+            except (AttributeError, OSError):
+                pass
+            threads = min(ncpu, 16)
             n_cpu_chains, cpu_iters = 256 * threads, 200        # ~1.2 s wall on 16 threads = ~19 s of CPU work
             v = cpu_baseline(n_cpu_chains, 100, cpu_iters, threads)
             v1 = cpu_baseline(64, 100, 200, 1)                   # ~0.4 s: one thread, 64 chains one after the other
+            allc = None
+            if ncpu > threads:                                   # "all-core total" — every core this process is allowed
+                va = cpu_baseline(64 * ncpu, 100, 100, ncpu)
+                allc = {"value": va, "unit": "iterations/s", "cores": ncpu,
+                        "sample": f"{64 * ncpu} funnel-10D chains x 100 draws after 100 warmup draws, {ncpu} threads (all cores of this process's affinity mask)"}
             out["cpu_baseline"] = {"value": v, "unit": "iterations/s", "cores": threads, "kind": "port",
                                    "sample": f"CPU oracle (C restatement of the reference path, OpenMP over chains): {n_cpu_chains} funnel-10D chains x {cpu_iters} draws after 100 warmup draws",
                                    "single_thread": {"value": v1, "unit": "iterations/s", "sample": "64 funnel-10D chains x 200 draws after 100 warmup draws, 1 thread"},
+                                   "all_cores": allc, "host_cpus_usable": ncpu,
                                    "cpu_model": cpu_model_string(), "host_cpus": os.cpu_count(),
                                    "reference_python": {"it_per_s_per_chain": [59.4, 78.4], "unit": "iterations/s per chain",
                                                         "where": "BASELINE.md section 2: the reference's own klhr_sinh.py, NumPy stand-in model, 1 core of the build container (the reference cannot travel to the GPU box)"}}
@@ -309,6 +408,9 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rccl_failed:
+        print(f"bench.py: the pooled shard's collective did not run over all ranks: {rccl_failed}", file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

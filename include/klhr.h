@@ -8,8 +8,11 @@
  * behind one C ABI and batches it over `chains` independent chains.  Each entry point below names
  * the reference interface it replaces.  Conventions: plain pointers and sizes, caller-owned HOST
  * buffers (row-major, chain-major: [chain][dim]), library-owned device buffers, `int` status
- * (0 = ok, <0 = error; see klhr_last_error), no exceptions, one host thread per handle, one HIP
- * stream per handle, a handle is bound to one device.
+ * (0 = ok, <0 = error; see klhr_last_error), no exceptions, one host thread per handle, a handle is
+ * bound to one device.  HIP streams are a per-device pool of four shared by every handle on the device
+ * (created once per process: see klhr_api.hip): handles on one device serialise in stream order, and
+ * klhr_sync / klhr_last_step_timing of one handle wait for / include work that another handle has put on
+ * the same streams — timing is meaningful only while no other handle of the device is active.
  *
  * There is NO CPU fallback: every compute entry point runs HIP kernels and fails with
  * KLHR_ERR_HIP when no gfx950 device is usable.
@@ -85,17 +88,21 @@ KLHR_API int klhr_create(const klhr_config *cfg, const double *model_data, size_
 KLHR_API void klhr_destroy(klhr_sampler *s);
 KLHR_API const char *klhr_last_error(const klhr_sampler *s);   /* s may be NULL: last create() error */
 KLHR_API int klhr_abi_version(void);
+/* sha256 of the library's sources (klhr_amd/build.py: source_hash) — names the build a profile was taken on
+ * (profiles/traffic.json; bench.py quotes measured HBM traffic only for the build that is loaded) */
+KLHR_API const char *klhr_build_id(void);
 KLHR_API int klhr_device_count(void);                          /* visible HIP devices (0 when none / no driver) */
 KLHR_API int klhr_dim(const klhr_sampler *s);                  /* replaces BSModel.dim() (bsmodel.py:39-40) */
 KLHR_API int klhr_chains(const klhr_sampler *s);
 KLHR_API int klhr_sync(klhr_sampler *s);                       /* wait for the handle's stream */
 /* which hot-path kernels this handle launches: 0 = octet-per-chain (klhr_iter_kernel), 1 = lane-per-chain
- * (klhr_lane_kernel, model dimension <= 26), 2 = split-phase pipeline (streaming kernel + klhr_fit12_kernel, i.e. both fit stages lane = chain;
- * klhr_fit1_kernel / klhr_fit2_kernel in the asynchronous and hand-over modes: funnel / ill-normal / normal / ar1 above dimension 26), 3 = split-phase pipeline with both fit stages in
- * the node-parallel klhr_fitn_kernel (up to 32 768 chains), 4 = as 2 with long KL fits handed to klhr_fit2r_kernel
- * (KLHR_FIT_RESUME=1), 5 = as 3, and klhr_step runs whole iterations per 16-chain tile in one launch (klhr_tile_kernel,
- * up to 8 192 chains; the pieces of the C ABI and diagnostic steps use the kernels of 3).  Results agree within the stated tolerances (2, 3, 4, 5: bit for bit); only the mapping to the machine
- * differs.  KLHR_KERNEL = octet | lane | mono | split in the environment overrides.
+ * (klhr_lane_kernel, model dimension <= 26), 2 = split-phase pipeline: streaming kernel + klhr_fit12_kernel (both fit
+ * stages lane = chain; funnel / ill-normal / normal / ar1 above dimension 26), 3 = split-phase pipeline with both fit
+ * stages in the node-parallel klhr_fitn_kernel (up to 32 768 chains), 5 = as 3, and klhr_step runs whole iterations per
+ * 16-chain tile in one launch (klhr_tile_kernel, up to 8 192 chains; the pieces of the C ABI and diagnostic steps use
+ * the kernels of 3).  (4 was the hand-over mode removed in round 3.)  Results agree within the stated tolerances
+ * (2, 3, 5: bit for bit); only the mapping to the machine differs.  KLHR_KERNEL = octet | lane | mono | split in the
+ * environment overrides.
  * klhr_tile_width: chains per tile of the split pipeline's state layout — 64 (klhr_stream_kernel) or 16
  * (klhr_stream16_kernel, up to 16 384 chains); 0 for the monolithic kernels. */
 KLHR_API int klhr_kernel_variant(const klhr_sampler *s);

@@ -50,6 +50,7 @@ def lib():
         "klhr_destroy": (None, [vp]),
         "klhr_last_error": (C.c_char_p, [vp]),
         "klhr_abi_version": (C.c_int, []),
+        "klhr_build_id": (C.c_char_p, []),
         "klhr_device_count": (C.c_int, []),
         "klhr_dim": (C.c_int, [vp]),
         "klhr_chains": (C.c_int, [vp]),
@@ -99,7 +100,7 @@ def lib():
     return L
 
 
-EXPORTS = ["klhr_create", "klhr_destroy", "klhr_last_error", "klhr_abi_version", "klhr_device_count", "klhr_dim", "klhr_chains", "klhr_sync",
+EXPORTS = ["klhr_create", "klhr_destroy", "klhr_last_error", "klhr_abi_version", "klhr_build_id", "klhr_device_count", "klhr_dim", "klhr_chains", "klhr_sync",
            "klhr_kernel_variant", "klhr_tile_width",
            "klhr_seed", "klhr_seed_state", "klhr_window_closures", "klhr_step", "klhr_get_draws", "klhr_reserve_draws", "klhr_random_direction",
            "klhr_fit", "klhr_metropolis", "klhr_adapt", "klhr_set_slice", "klhr_slice_step", "klhr_kl_eval", "klhr_line_eval", "klhr_log_density_gradient",
@@ -111,6 +112,11 @@ EXPORTS = ["klhr_create", "klhr_destroy", "klhr_last_error", "klhr_abi_version",
 
 def device_count():
     return lib().klhr_device_count()
+
+
+def build_id():
+    """sha256 of the sources the loaded library was built from (klhr_build_id)"""
+    return lib().klhr_build_id().decode()
 
 
 def comm_unique_id():
@@ -220,7 +226,6 @@ class Sampler:
         stream = "klhr_stream16_kernel" if self._L.klhr_tile_width(self._h) == 16 else "klhr_stream_kernel"
         return {0: ["klhr_iter_kernel"], 1: ["klhr_lane_kernel"], 2: [stream, "(none)", "klhr_fit12_kernel"],
                 3: [stream, "(none)", "klhr_fitn_kernel"],
-                4: [stream, "klhr_fit1_kernel", "klhr_fit2_kernel+klhr_fit2r_kernel"],
                 5: ["klhr_tile_kernel"]}[self._L.klhr_kernel_variant(self._h)]
 
     def kernel_name(self):

@@ -24,6 +24,18 @@ RETRY_FLAGS = ["-mllvm", "-greedy-regclass-priority-trumps-globalness=1"]
 LINT = os.path.join(HERE, "..", "tools", "exec_lint.py")
 
 
+def source_hash():
+    """sha256 (hex) of the library's sources — every file of DEPS, by name and content.  Compiled into the library as
+    klhr_build_id() and stored with every profiles/traffic.json entry: bench.py reports measured HBM traffic only when the
+    entry was taken on the build that is loaded (evidence of a kernel that no longer exists must not be quoted)."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in sorted(DEPS):
+        with open(os.path.join(SRC, d), "rb") as f:
+            h.update(os.path.basename(d).encode() + b"\0" + f.read() + b"\0")
+    return h.hexdigest()
+
+
 def _lint(objdir):
     """Flagged blocks in the device assembly that -save-temps left in objdir (empty list = clean).  Fails closed: a unit
     whose device assembly cannot be found (toolchain naming change, flags that drop -save-temps) is an error, not "clean"."""
@@ -54,7 +66,7 @@ def build(force=False, verbose=False, extra=()):
     os.makedirs(OBJ, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = FLAGS + list(extra) + (["-Rpass-analysis=kernel-resource-usage"] if verbose else [])
-    jobs = [("api.o", ["-c", os.path.join(SRC, "klhr_api.hip")])]
+    jobs = [("api.o", ["-c", os.path.join(SRC, "klhr_api.hip"), f'-DKLHR_BUILD_ID="{source_hash()}"'])]
     for v in (0, 1, 2):
         for o in (0, 1):
             jobs.append((f"hot_v{v}_o{o}.o", ["-c", os.path.join(SRC, "klhr_hot.hip"), f"-DKLHR_VARIANT={v}", f"-DKLHR_OVERRELAX={o}"]))

@@ -1,6 +1,6 @@
 // klhr_api.hip — host side of libklhr_hip.so: the C ABI declared in include/klhr.h.
 //
-// Owns all device memory of a sampler handle (chain-major SoA in HBM), one HIP stream per handle, and
+// Owns all device memory of a sampler handle (chain-major SoA in HBM; the HIP streams are a per-device pool shared by all handles), and
 // launches the gfx950 kernels of klhr_kernels.hpp.  No PyTorch, no CPU fallback: every compute entry
 // point fails with KLHR_ERR_HIP when the device is unusable.
 #include <hip/hip_runtime.h>
@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -22,7 +23,7 @@ void launch_hot_v1_o1(const KParams &, int, bool, hipStream_t);
 void launch_hot_v2_o0(const KParams &, int, bool, hipStream_t);
 void launch_hot_v2_o1(const KParams &, int, bool, hipStream_t);
 void launch_hot_v3_o0(const KParams &, int, bool, hipStream_t);
-// split-phase pipeline (klhr_split.hip), one unit per variant: what = 0 stream, 1 mode search, 2 KL fit, 3 probe
+// split-phase pipeline (klhr_split.hip), one unit per variant: what = 0 stream, 3 probe, 4 / 8 fit, 7 whole iterations per tile
 void launch_split_v0(const KParams &, int, int, bool, int, int, hipStream_t);
 void launch_split_v1(const KParams &, int, int, bool, int, int, hipStream_t);
 void launch_split_v2(const KParams &, int, int, bool, int, int, hipStream_t);
@@ -70,8 +71,10 @@ RcclApi &rccl() {
 // carry the chain groups of the split pipeline.  Handles used at the same time share the streams: their work interleaves
 // in stream order, which is correct (every call forks and joins through events) if not concurrent.
 static hipStream_t g_stream_pool[64][4];
+static std::mutex g_stream_pool_mutex;          // handles may be created from several host threads
 static int stream_from_pool(int device, int slot, hipStream_t *out) {
     if (device < 0 || device >= 64 || slot < 0 || slot >= 4) return -1;
+    std::lock_guard<std::mutex> lock(g_stream_pool_mutex);
     if (!g_stream_pool[device][slot]) {
         // all four at once, at the first handle of the process on this device: created later, after other work had gone
         // through the device, the group streams shared hardware queues (funnel-100 x 131 072: 0.87e8 instead of 1.36e8 it/s)
@@ -98,12 +101,9 @@ struct klhr_sampler {
     double *d_gram = nullptr, *d_pool = nullptr;
     void *comm = nullptr;
     int comm_rank = 0, comm_world = 0;
-    bool async_ok = false;       // klhr_step lets chains progress asynchronously (split pipeline)
     bool fitn = false;           // split pipeline: both fit stages in the node-parallel kernel (few chains: klhr_fitn_kernel)
-    bool resume = false;         // split pipeline, many chains: long KL fits are handed to the node-parallel resume kernel
     bool last_fused = false;     // the most recent klhr_step ran as one klhr_tile_kernel launch
     bool fused = false;          // split pipeline, few chains: whole iterations per tile in one launch (klhr_tile_kernel)
-    unsigned int *h_pend = nullptr;      // pinned host copy of the groups' pending-chain counters
     bool profile = false;
     std::vector<hipEvent_t> pev;
     int pev_used = 0;
@@ -205,6 +205,10 @@ extern "C" int klhr_window_closures(int64_t warmup, int64_t windowsize, int64_t 
 }
 
 extern "C" int klhr_abi_version(void) { return KLHR_ABI_VERSION; }
+#ifndef KLHR_BUILD_ID
+#define KLHR_BUILD_ID "unknown"
+#endif
+extern "C" const char *klhr_build_id(void) { return KLHR_BUILD_ID; }
 extern "C" int klhr_device_count(void) {
     int n = 0;
     return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
@@ -213,7 +217,7 @@ extern "C" const char *klhr_last_error(const klhr_sampler *s) { return s ? s->er
 extern "C" int klhr_dim(const klhr_sampler *s) { return s ? s->D : KLHR_ERR_ARG; }
 extern "C" int klhr_chains(const klhr_sampler *s) { return s ? s->C : KLHR_ERR_ARG; }
 extern "C" int klhr_tile_width(const klhr_sampler *s) { return s ? (s->split ? s->tw : 0) : KLHR_ERR_ARG; }
-extern "C" int klhr_kernel_variant(const klhr_sampler *s) { return s ? (s->split ? (s->fused ? 5 : (s->fitn ? 3 : (s->resume ? 4 : 2))) : (s->use_lane ? 1 : 0)) : KLHR_ERR_ARG; }
+extern "C" int klhr_kernel_variant(const klhr_sampler *s) { return s ? (s->split ? (s->fused ? 5 : (s->fitn ? 3 : 2)) : (s->use_lane ? 1 : 0)) : KLHR_ERR_ARG; }
 
 // ---- host <-> device copies of [C][W] state arrays: the host side is always chain-major (the NumPy layout); the device
 // side is tiled [tile][w][64 lanes] for handles of the split pipeline
@@ -250,8 +254,6 @@ static int reset_state(klhr_sampler *s) {
     HIPCHECK(s, hipMemcpyAsync(k.eigvals, ones.data(), Cc * nc * 8, hipMemcpyHostToDevice, s->stream));
     if (k.fitbuf) {
         HIPCHECK(s, hipMemsetAsync(k.fitbuf, 0, (size_t)F_NFIELDS * C * 8, s->stream));
-        HIPCHECK(s, hipMemsetAsync(k.phase, 0, C * 4, s->stream));
-        HIPCHECK(s, hipMemsetAsync(k.togo, 0, C * 4, s->stream));
     }
     HIPCHECK(s, hipMemsetAsync(k.theta, 0, C * D * 8, s->stream));
     HIPCHECK(s, hipMemsetAsync(k.mean, 0, C * D * 8, s->stream));
@@ -395,43 +397,17 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
     k.draw_stride = (long long)s->C * D;
     if (s->split) {
         TRY(dalloc(s, &k.fitbuf, (size_t)F_NFIELDS * C));
-        TRY(dalloc(s, &k.phase, C)); TRY(dalloc(s, &k.togo, C)); TRY(dalloc(s, &k.pend, 16));
-        { Opt *ob = nullptr; TRY(dalloc(s, &ob, C)); k.optbuf = ob; }
-        // Asynchronous chains in klhr_step (opt-in, KLHR_ASYNC=1; pass budgets KLHR_FIT_BUDGET1 / KLHR_FIT_BUDGET2).  Measured on
-        // funnel-100 x 131 072 and ill-normal-100 x 16 384: 1.33e8 vs 1.36e8 and 5.7e7 vs 6.1e7 it/s against the synchronous
-        // rounds — with the chains in 2-4 groups on their own streams the idle tail of one group's fit launch is already
-        // filled by the other groups' kernels, and the drain rounds at the end of a call cost more than the budget saves.
-        // A chain whose fits are persistently long bounds the call either way (it has to finish its own n draws).
-        k.async_mode = 0; k.budget1 = 12; k.budget2 = 28;
-        s->async_ok = false;
-        if (const char *e = getenv("KLHR_ASYNC")) s->async_ok = atoi(e) != 0;
         // few chains: the fit's latency (its slowest chain's sequence of passes) is the launch's duration — 8 lanes per chain
         // shorten the pass (klhr_split.hpp: klhr_fitn_kernel).  Measured, ill-normal-100, both stages: 16 384 chains 77 us against
         // 159, 32 768: 118 / 171, 65 536: 204 / 183, funnel-100 x 131 072: 952 / 676 — from 65 536 chains on lane = chain has the throughput
         s->fitn = C <= 32768;
         if (const char *e = getenv("KLHR_FITN")) s->fitn = atoi(e) != 0;
-        // many chains (opt-in, KLHR_FIT_RESUME=1, budget KLHR_FIT_RESUME_BUDGET): the lane = chain KL fit stops at a pass budget and
-        // hands the unfinished fits (the thin long tail: funnel-100 median 13 passes, 1 % >= 28, rare 60-75) to the node-parallel
-        // resume kernel.  Measured on funnel-100 x 131 072: KL fit 634 us -> 266 + 221 us (budget 14) with one chain group, but
-        // 918 vs 920 us per iteration with the default four groups — the other groups' kernels already fill the SIMDs that a
-        // fit launch's tail leaves idle, and the tail's own latency (60 passes x 3 us) stays.  (A second lane = chain launch over
-        // the compact hand-over list before the node-parallel one, budgets 22-32 / 10-16: 1.23-1.31e8 against 1.38e8 it/s — the
-        // 720-byte optimiser records written and read per handed-over chain cost more than the idle lanes.)  Off by default.
-        TRY(dalloc(s, &k.resume_list, C)); TRY(dalloc(s, &k.resume_count, 16));
-        TRY(hip_try(hipMemsetAsync(k.resume_count, 0, 16 * sizeof(unsigned int), s->stream), "hipMemsetAsync"));
-        s->resume = false;
-        if (const char *e = getenv("KLHR_FIT_RESUME")) s->resume = atoi(e) != 0 && !s->fitn;
-        k.resume_budget = 16;
-        if (const char *e = getenv("KLHR_FIT_RESUME_BUDGET")) { const int v = atoi(e); if (v >= 1) k.resume_budget = v; }
-        if (!s->resume) k.resume_budget = 0;
         // few chains: klhr_step runs whole iterations per 16-chain tile in ONE launch (klhr_tile_kernel: the pair-mode streaming
         // body and the node-parallel fit body in a loop over the draws, one workgroup per tile).  Needs what those two need.
         // One wavefront per SIMD by register count: up to 8 192 chains (1 024 wavefronts); measured in klhr_split.hpp.
         const bool fused_ok = s->tw == 16 && s->fitn && ((size_t)2 * D * 16 + 512 + 65) * 8 <= 160 * 1024;
         s->fused = fused_ok && s->C <= 8192;
-        if (const char *e = getenv("KLHR_FUSED")) s->fused = atoi(e) == 2 ? fused_ok : (s->fused && atoi(e) != 0);      // (2: whatever the chain count)
-        if (const char *e = getenv("KLHR_FIT_BUDGET1")) { const int v = atoi(e); if (v >= 1) k.budget1 = v; }
-        if (const char *e = getenv("KLHR_FIT_BUDGET2")) { const int v = atoi(e); if (v >= 1) k.budget2 = v; }
+        if (const char *e = getenv("KLHR_FUSED")) s->fused = s->fused && atoi(e) != 0;      // (0: the kernel sequence; used by the parity tests)
         // Chain groups of klhr_step: the streaming kernel is bound by memory, the fit kernels by the fp64 ALUs; with the chains
         // in two groups on two HIP streams one group's fit overlaps the other group's streaming.  (Tuning aid: KLHR_GROUPS.)
         s->groups = s->C >= 32768 ? 4 : (s->C >= 8192 ? 2 : 1);          // (measured: funnel-100 x 131 072: 1.0e8 / 1.2e8 / 1.4e8 it/s with 1 / 2 / 4 groups)
@@ -454,8 +430,6 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
         // (159 with two chain groups), 32 768: 296 -> 311 (second round of wavefronts: off).
         k.stream_pair = s->C <= 16384;
         if (const char *e = getenv("KLHR_STREAM_PAIR")) k.stream_pair = atoi(e) != 0;
-        k.fit_lanes = 0;           // 0: chosen per launch from the chain count of the launch (klhr_split.hip)
-        if (const char *e = getenv("KLHR_FIT_LANES")) { const int v = atoi(e); if (v == 8 || v == 16 || v == 32 || v == 64) k.fit_lanes = v; }
     }
     k.flags = (cfg->scale_dir_cov ? FLAG_SCALE_DIR_COV : 0) | (cfg->eigen_method_one ? FLAG_EIGEN_ONE : 0) |
               (cfg->overrelaxed ? FLAG_OVERRELAXED : 0);
@@ -499,7 +473,6 @@ extern "C" void klhr_destroy(klhr_sampler *s) {
     if (!s) return;
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (hipEvent_t e : s->pev) (void)hipEventDestroy(e);
-    if (s->h_pend) (void)hipHostFree(s->h_pend);
     if (s->comm && rccl().ok) (void)rccl().CommDestroy((ncclComm_t)s->comm);
     if (s->d_gram) (void)hipFree(s->d_gram);
     if (s->d_pool) (void)hipFree(s->d_pool);
@@ -562,8 +535,6 @@ static bool group_view(const klhr_sampler *s, const KParams &kp, int g, int G, K
     out.acc += c0; out.grad_evals += c0; out.status += c0; out.d_diag += c0 * KLHR_NDIAG;
     out.fitbuf += c0;
     if (out.draws) out.draws += c0 * D;
-    out.phase += c0; out.togo += c0; out.optbuf = reinterpret_cast<Opt *>(out.optbuf) + c0; out.pend += g;
-    out.resume_list += c0; out.resume_count += g;
     return true;
 }
 
@@ -597,8 +568,6 @@ static int run_phases(klhr_sampler *s, int phases, int64_t n_iters, int record_d
             KParams kp = s->kp;
             kp.phases = phases;
             kp.n_iters = (int)((n_iters - done) < chunk ? (n_iters - done) : chunk);
-            kp.async_mode = 0;
-            kp.resume_budget = 0;
             kp.draws = record_draws ? s->d_draws + (size_t)done * s->C * s->D : nullptr;
             launch_split(s, kp, 7, 1, 1, s->stream);
             HIPCHECK(s, hipGetLastError());
@@ -620,70 +589,30 @@ static int run_phases(klhr_sampler *s, int phases, int64_t n_iters, int record_d
         // per-kernel profiling runs one group so that the kernels of an iteration follow each other on one stream
         const int G = (phases == PH_ALL && !record_diag && !s->profile) ? s->groups : 1;
         const bool prof = s->profile && phases == PH_ALL;
-        const bool async = phases == PH_ALL && !record_diag && !s->profile && s->async_ok;
         if (prof) {
             const size_t need = (size_t)(n_iters + 1) * 4;
             while (s->pev.size() < need) { hipEvent_t e; HIPCHECK(s, hipEventCreate(&e)); s->pev.push_back(e); }
             s->pev_used = 0;
         }
-        auto mark = [&](int slot) -> int { if (prof) { HIPCHECK(s, hipEventRecord(s->pev[slot], s->stream)); s->pev_used = slot + 1; } return 0; };
         HIPCHECK(s, hipEventRecord(s->ev0, s->stream));
         if (G > 1) {
             HIPCHECK(s, hipEventRecord(s->ev_fork, s->stream));
             for (int g = 1; g < G; g++) HIPCHECK(s, hipStreamWaitEvent(s->gstream[g], s->ev_fork, 0));
         }
-        if (async) {
-            // Asynchronous chains: n_iters + 1 rounds of [streaming kernel, mode search, KL fit]; every chain takes part in a
-            // launch according to its own phase, fits are cut at their pass budget and resumed in the next round.  Then drain
-            // rounds until no chain has work left (a chain loses one round per resumed fit: a few rounds, checked on the host).
-            if (!s->h_pend) HIPCHECK(s, hipHostMalloc((void **)&s->h_pend, 16 * sizeof(unsigned int), 0));
-            KParams kp0 = s->kp;
-            kp0.phases = phases;
-            kp0.n_iters = (int)n_iters;
-            kp0.async_mode = 1;
-            kp0.draws = record_draws ? s->d_draws : nullptr;
-            KParams kpg[4];
-            bool have[4] = {false, false, false, false};
-            for (int g = 0; g < G; g++) {
-                have[g] = group_view(s, kp0, g, G, kpg[g]);
-                if (!have[g]) continue;
-                hipStream_t st = g == 0 ? s->stream : s->gstream[g];
-                HIPCHECK(s, hipMemsetD32Async((hipDeviceptr_t)kpg[g].togo, (int)n_iters, (size_t)kpg[g].C, st));
-            }
-            auto round = [&](int g) {
-                hipStream_t st = g == 0 ? s->stream : s->gstream[g];
-                launch_split(s, kpg[g], 0, 1, 1, st);
-                launch_split(s, kpg[g], 1, 0, 0, st);
-                launch_split(s, kpg[g], 2, 0, 0, st);
-            };
-            for (int64_t it = 0; it <= n_iters; it++) {
-                for (int g = 0; g < G; g++) if (have[g]) round(g);
-                HIPCHECK(s, hipGetLastError());
-            }
-            bool todo[4] = {have[0], have[1], have[2], have[3]};
-            for (int guard = 0; guard < 100000; guard++) {
-                bool any = false;
-                for (int g = 0; g < G; g++) {
-                    if (!todo[g]) continue;
-                    any = true;
-                    hipStream_t st = g == 0 ? s->stream : s->gstream[g];
-                    HIPCHECK(s, hipMemsetAsync(kpg[g].pend, 0, sizeof(unsigned int), st));
-                    round(g);
-                    HIPCHECK(s, hipMemcpyAsync(&s->h_pend[g], kpg[g].pend, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
-                }
-                if (!any) break;
-                for (int g = 0; g < G; g++) {
-                    if (!todo[g]) continue;
-                    HIPCHECK(s, hipStreamSynchronize(g == 0 ? s->stream : s->gstream[g]));
-                    if (s->h_pend[g] == 0) todo[g] = false;
-                }
-            }
-        } else
-        for (int64_t it = 0; it <= n_iters; it++) {
+        // (an error between the fork and the join must not leave the group streams unjoined for the next call: the loop records
+        //  the first failure, the join below runs in every case)
+        int rc_loop = KLHR_OK;
+        auto hipok = [&](hipError_t e, const char *what) {
+            if (e == hipSuccess || rc_loop != KLHR_OK) return e == hipSuccess;
+            s->err = std::string(what) + " failed: " + hipGetErrorString(e);
+            rc_loop = KLHR_ERR_HIP;
+            return false;
+        };
+        auto mark = [&](int slot) { if (prof && hipok(hipEventRecord(s->pev[slot], s->stream), "hipEventRecord")) s->pev_used = slot + 1; };
+        for (int64_t it = 0; it <= n_iters && rc_loop == KLHR_OK; it++) {
             KParams kp0 = s->kp;
             kp0.phases = phases;
             kp0.n_iters = 1;
-            kp0.async_mode = 0;
             if (record_diag) kp0.flags |= FLAG_DIAG;
             const int do_tail = it > 0 && tailp, do_head = it < n_iters && headp;
             kp0.draws = (record_draws && do_tail) ? s->d_draws : nullptr;
@@ -692,16 +621,13 @@ static int run_phases(klhr_sampler *s, int phases, int64_t n_iters, int record_d
                 KParams kp;
                 if (!group_view(s, kp0, g, G, kp)) continue;
                 hipStream_t st = g == 0 ? s->stream : s->gstream[g];
-                if (mark((int)it * 4 + 0)) return KLHR_ERR_HIP;
+                mark((int)it * 4 + 0);
                 if (do_tail || do_head) launch_split(s, kp, 0, do_tail, do_head, st);
-                if (mark((int)it * 4 + 1)) return KLHR_ERR_HIP;
+                mark((int)it * 4 + 1);
                 if (it < n_iters && (phases & PH_FIT)) {
-                    const bool two_launches = !s->fitn && kp.resume_budget;        // (the hand-over list is zeroed by the mode-search kernel)
-                    if (two_launches) launch_split(s, kp, 1, 0, 0, st);
-                    if (mark((int)it * 4 + 2)) return KLHR_ERR_HIP;
-                    launch_split(s, kp, s->fitn ? 4 : (two_launches ? 2 : 8), 0, 0, st);
-                    if (two_launches) launch_split(s, kp, 5, 0, 0, st);
-                    if (mark((int)it * 4 + 3)) return KLHR_ERR_HIP;
+                    mark((int)it * 4 + 2);
+                    launch_split(s, kp, s->fitn ? 4 : 8, 0, 0, st);          // both fit stages: node-parallel (few chains) or lane = chain
+                    mark((int)it * 4 + 3);
                 }
                 if (it < n_iters && (phases & (PH_KL | PH_LINE))) {
                     const char *rep = getenv("KLHR_PROBE_REPEAT");
@@ -709,12 +635,13 @@ static int run_phases(klhr_sampler *s, int phases, int64_t n_iters, int record_d
                     launch_split(s, kp, 3, 0, 0, st);
                 }
             }
-            HIPCHECK(s, hipGetLastError());
+            hipok(hipGetLastError(), "kernel launch");
         }
         for (int g = 1; g < G; g++) {
-            HIPCHECK(s, hipEventRecord(s->gev[g], s->gstream[g]));
-            HIPCHECK(s, hipStreamWaitEvent(s->stream, s->gev[g], 0));
+            hipok(hipEventRecord(s->gev[g], s->gstream[g]), "hipEventRecord");
+            hipok(hipStreamWaitEvent(s->stream, s->gev[g], 0), "hipStreamWaitEvent");
         }
+        if (rc_loop != KLHR_OK) return rc_loop;
         HIPCHECK(s, hipEventRecord(s->ev1, s->stream));
         s->timing_pending = true;
         s->last_launches = (int)n_iters;
@@ -802,7 +729,7 @@ extern "C" int klhr_last_kernel_times(klhr_sampler *s, double ms3[3], int n3[3])
             HIPCHECK(s, hipEventElapsedTime(&ms, s->pev[it * 4 + k], s->pev[it * 4 + k + 1]));
             tot[k] += ms; n3[k] += 1;
         }
-    if (s->fitn || !s->resume) { tot[1] = 0; n3[1] = 0; }          // (one kernel runs both stages: slot 2)
+    tot[1] = 0; n3[1] = 0;          // (one kernel runs both fit stages: slot 2; slot 1 is kept for the ABI's layout)
     for (int k = 0; k < 3; k++) ms3[k] = n3[k] ? tot[k] / n3[k] : 0;
     return KLHR_OK;
 }
@@ -1270,12 +1197,8 @@ extern "C" int klhr_pool_allreduce(klhr_sampler *s) {
     const int D = s->D, Dp = ((D + 1 + 15) / 16) * 16, n = 1 + D + D * D;
     hipLaunchKernelGGL(klhr_gram_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->d_gram, D, Dp, s->d_pool);
     HIPCHECK(s, hipGetLastError());
-    if (s->comm && s->comm_world > 1) {
-        RcclApi &r = rccl();
-        const ncclResult_t nrc = r.AllReduce(s->d_pool, s->d_pool, (size_t)n, ncclDouble, ncclSum, (ncclComm_t)s->comm, s->stream);
-        if (nrc != ncclSuccess) { s->err = std::string("ncclAllReduce failed: ") + r.GetErrorString(nrc); return KLHR_ERR_HIP; }
-    } else if (s->comm) {
-        // a one-rank communicator: still goes through RCCL (the path the multi-GPU job takes; used by the 1-GPU test)
+    if (s->comm) {
+        // (a one-rank communicator goes through RCCL as well: the path the multi-GPU job takes, exercised by the 1-GPU test)
         RcclApi &r = rccl();
         const ncclResult_t nrc = r.AllReduce(s->d_pool, s->d_pool, (size_t)n, ncclDouble, ncclSum, (ncclComm_t)s->comm, s->stream);
         if (nrc != ncclSuccess) { s->err = std::string("ncclAllReduce failed: ") + r.GetErrorString(nrc); return KLHR_ERR_HIP; }

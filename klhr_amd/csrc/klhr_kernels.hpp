@@ -69,32 +69,12 @@ struct KParams {
     long long fstride;           // field stride of fitbuf (the handle's padded chain count)
     long long draw_stride;       // doubles between two recorded iterations in `draws` (handle's chains x D)
     double *fitbuf;              // per-chain fit records, SoA [F_NFIELDS][fstride]
-    int fit_lanes;               // fit / probe kernels: chains per wavefront (64, 32, 16 or 8; the other lanes leave at once)
-    int stream_pair;             // streaming kernel: two wavefronts per tile (tail | head), narrow tiles in the synchronous rounds (klhr_split.hpp)
+    int stream_pair;             // streaming kernel: two wavefronts per tile (tail | head), narrow tiles (klhr_split.hpp)
     int stream_waves;            // streaming kernel: wavefronts (tiles) per workgroup, sharing one LDS copy of the ziggurat tables
-    // asynchronous chains (klhr_step on the split pipeline): every chain advances through head -> mode search -> KL fit ->
-    // tail at its own pace.  A fit launch gives every chain at most `budget` objective passes; a chain that is not done keeps
-    // its optimiser state in optbuf and goes on in the next round, while the other chains of the launch move on.
-    int async_mode;              // 0: every launch processes every chain to completion (C-ABI pieces, diagnostics, profiling)
-    int budget1, budget2;        // passes per launch of the mode search / the KL fit in async mode
-    int *phase;                  // per chain: PHS_* below
-    void *optbuf;                // per chain: saved optimiser state (struct Opt) of a fit in progress
-    int *togo;                   // per chain: draws of this klhr_step call (n_iters of them) still to be completed;
-                                 // a recorded draw goes to slot n_iters - togo
-    unsigned int *pend;          // [1] chains that still have work after this streaming launch (async mode)
-    // synchronous rounds, many chains: the lane = chain KL fit gives a chain resume_budget passes; the few per cent that need
-    // more are listed and finished by the node-parallel resume kernel (klhr_fit2r_kernel) instead of holding their wavefront
-    int resume_budget;           // 0: off
-    int *resume_list;            // [chains of the launch] chain indices (within the launch) whose KL fit is to be resumed
-    unsigned int *resume_count;  // [1] entries of resume_list; zeroed by the mode-search kernel of the same round
 };
-// phase of a chain between two launches (async mode)
-enum { PHS_HEAD = 0,             // needs the head of its next iteration (or is finished: draw == target)
-       PHS_FIT1 = 1, PHS_FIT1_RESUME = 11, PHS_FIT2 = 2, PHS_FIT2_RESUME = 12,
-       PHS_TAIL = 3 };           // its fit is complete: needs the tail (MH, adaptation, draw output)
 
 // per-chain fit record of the split pipeline, SoA: field f of chain c at fitbuf[f * Cpad + c]
-enum { F_S0 = 0, F_S1, F_S2, F_S3, F_S4, F_S5, F_S6, F_NN, F_X0, F_N2, F_N3, F_MODE, F_INIT1, F_PASS, F_NFEV1, F_NFEV2, F_PASS1, F_NFIELDS };
+enum { F_S0 = 0, F_S1, F_S2, F_S3, F_S4, F_S5, F_S6, F_NN, F_X0, F_N2, F_N3, F_MODE, F_INIT1, F_PASS, F_NFEV1, F_NFEV2, F_NFIELDS };
 
 // index of coordinate i (and column j of ncol) of chain c in a [C][D] / [C][D][ncol] state array, either layout
 __device__ __forceinline__ long long kix(const KParams &p, long long c, int i) {

@@ -16,25 +16,18 @@ namespace klhr {
 template <int MODEL>
 static void launch_split_model(const KParams &kp0, int what, bool overrelaxed, int do_tail, int do_head, hipStream_t stream) {
     constexpr int V = KLHR_VARIANT;
-    // fit / probe kernels: lane = chain, fit_lanes chains per wavefront (KLHR_FIT_LANES; 64).  Measured at 16 384 chains: 64, 32
-    // and 16 chains per wavefront take the same time (a launch lasts as long as its slowest chain's sequence of passes, on
-    // however many SIMDs), 8 take twice as long — few chains go to the node-parallel kernel (what == 4) instead.
+    // fit / probe kernels: lane = chain, 64 chains per wavefront (few chains go to the node-parallel kernel, what == 4)
     KParams kp = kp0;
-    if (kp.fit_lanes <= 0) kp.fit_lanes = 64;
-    const unsigned tiles = (unsigned)((kp.C + kp.fit_lanes - 1) / kp.fit_lanes);
+    const unsigned tiles = (unsigned)((kp.C + 63) / 64);
     const unsigned stiles = (unsigned)(kp.Cpad / kp.tw);          // streaming kernel: one wavefront per tile of tw chains,
     // pair mode (two wavefronts per tile, klhr_split.hpp): a launch that runs a tail AND a head on narrow tiles, synchronous rounds
-    if (kp.stream_pair && kp.tw == 16 && do_tail && do_head && !kp.async_mode && kp.stream_waves >= 2) kp.stream_waves &= ~1;
+    if (kp.stream_pair && kp.tw == 16 && do_tail && do_head && kp.stream_waves >= 2) kp.stream_waves &= ~1;
     else kp.stream_pair = 0;
     const unsigned tiles_wg = kp.stream_pair ? kp.stream_waves / 2 : kp.stream_waves;
     const unsigned sgroups = (stiles + tiles_wg - 1) / tiles_wg;                    // tiles_wg tiles per workgroup
     const dim3 block(64), sblock(64 * kp.stream_waves);
     const unsigned fitgrid = tiles;
-    if (what == 1) {
-        hipLaunchKernelGGL((klhr_fit1_kernel<MODEL>), dim3(fitgrid), block, 0, stream, kp);
-    } else if (what == 2) {
-        hipLaunchKernelGGL((klhr_fit2_kernel<MODEL, V>), dim3(fitgrid), block, 0, stream, kp);
-    } else if (what == 8) {
+    if (what == 8) {
         hipLaunchKernelGGL((klhr_fit12_kernel<MODEL, V>), dim3(fitgrid), block, 0, stream, kp);
     } else if (what == 7) {
         // whole iterations per tile (klhr_tile_kernel): one workgroup of two wavefronts per 16-chain tile, kp.n_iters draws
@@ -47,10 +40,6 @@ static void launch_split_model(const KParams &kp0, int what, bool overrelaxed, i
             if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)klhr_tile_kernel<MODEL, false, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL((klhr_tile_kernel<MODEL, false, V>), dim3(stiles), dim3(128), lds, stream, kp);
         }
-    } else if (what == 5) {
-        unsigned grid = (unsigned)((kp.C + 7) / 8);
-        if (grid > 2048) grid = 2048;           // (grid-stride over the list: the handed-over fits are a few per cent of the chains)
-        hipLaunchKernelGGL((klhr_fit2r_kernel<MODEL, V>), dim3(grid), block, 0, stream, kp);
     } else if (what == 4) {
         hipLaunchKernelGGL((klhr_fitn_kernel<MODEL, V>), dim3((unsigned)((kp.C + 7) / 8)), block, 0, stream, kp);
     } else if (what == 3) {
@@ -68,9 +57,8 @@ static void launch_split_model(const KParams &kp0, int what, bool overrelaxed, i
     }
 }
 
-// what: 0 streaming kernel (do_tail / do_head), 1 mode search, 2 KL fit, 3 KL / line probe, 4 both fit stages node-parallel,
-// 5 node-parallel resume of the KL fits klhr_fit2_kernel handed over, 7 whole iterations per tile (kp.n_iters draws in one launch),
-// 8 both fit stages lane = chain in one launch
+// what: 0 streaming kernel (do_tail / do_head), 3 KL / line probe, 4 both fit stages node-parallel (klhr_fitn_kernel),
+// 7 whole iterations per tile (kp.n_iters draws in one launch), 8 both fit stages lane = chain in one launch (klhr_fit12_kernel)
 void KLHR_CAT2(launch_split_v, KLHR_VARIANT)(const KParams &kp, int model_id, int what, bool overrelaxed, int do_tail, int do_head, hipStream_t stream) {
     switch (model_id) {
     case KLHR_MODEL_FUNNEL: launch_split_model<MODEL_FUNNEL>(kp, what, overrelaxed, do_tail, do_head, stream); break;

@@ -9,18 +9,17 @@
 // max_i |g_i(t)| <= clip, which the two maxima bound; the rare evaluation where that bound fails (measured on the
 // reference: 1 in 2 000-5 000 KL evaluations) is recomputed by the exact element-wise loop, so clipping semantics are kept.
 //
-// With the fit reduced to O(1) state per chain the iteration splits into three kernels with the mapping each part wants:
-//   klhr_stream_kernel  lane = chain, wavefront = tile of 64 chains.  Everything that is O(D) per chain and sequential
+// With the fit reduced to O(1) state per chain the iteration splits into two kernels with the mapping each part wants:
+//   klhr_stream_kernel  lane = chain, wavefront = tile of 64 (or 16) chains.  Everything that is O(D) per chain and sequential
 //                       in the coordinate index (NumPy's summation orders, the PCG64 stream): MH accept/reject + theta
 //                       update + OnlineMoments + CCIPCA (+ window closure) of iteration k, then the direction draw, the
 //                       line sums and the fit's five normals of iteration k+1.  The chain state lives in HBM in a TILED
-//                       layout [tile][coordinate][64 lanes]: lane-per-chain access to coordinate i of 64 chains is one
-//                       contiguous 512-byte segment.  This kernel moves all the algorithmic bytes of an iteration.
-//   klhr_fit1_kernel    the 1-D mode search (klhr_sinh.py:183-187), opt_advance<N = 1>
-//   klhr_fit2_kernel    the KL fit (klhr_sinh.py:194-199), opt_advance<N = 4 | 3 | 2>, 8 Gauss-Hermite nodes per lane
-//                       Both fit kernels are lane-per-task with a device-side QUEUE: a lane whose fit has converged
-//                       claims the next chain (wave-aggregated atomic) instead of idling until the slowest chain of
-//                       its wavefront is done.  Which lane runs a chain has no influence on the chain's arithmetic.
+//                       layout [tile][coordinate][W lanes]: lane-per-chain access to coordinate i of a tile is one
+//                       contiguous segment.  This kernel moves all the algorithmic bytes of an iteration.
+//   klhr_fit12_kernel   (many chains) lane = chain: the 1-D mode search (klhr_sinh.py:183-187, opt_advance<N = 1>), then the KL
+//                       fit (klhr_sinh.py:194-199, opt_advance<N = 4 | 3 | 2>, 8 Gauss-Hermite nodes per lane)
+//   klhr_fitn_kernel    (few chains) the same two stages with 8 lanes per chain, one quadrature node each
+//   klhr_tile_kernel    (fewest chains) whole iterations of a 16-chain tile — streaming body + node-parallel fit body — in one launch
 // Results: RNG stream, direction, OnlineMoments, CCIPCA, closures bit-exact as in the monolithic kernels; objective values
 // agree with the element-wise loops to rounding (closed form instead of a D-term sum), inside the stated tolerances.
 #pragma once
@@ -190,39 +189,27 @@ __device__ __forceinline__ void split_eval_kl(const KParams &p, const LineStat &
 }
 
 // ------------------------------------------------------------------------------------------------
-// The fit kernels: lane = chain (64 chains per wavefront, static).  In async mode (KParams::async_mode) a launch gives every
-// chain at most `budget` passes: a chain whose fit has not converged by then writes its optimiser state to optbuf and resumes
-// in the next round, so that a fit of 80 passes (line-search fallbacks; one chain in a few thousand) costs that chain three
-// rounds instead of costing every chain of the launch the wait.  Which round a pass runs in has no influence on its arithmetic.
-__device__ __forceinline__ void opt_save(const KParams &p, long long c, const Opt &o, int npass) {
-    Opt *dst = reinterpret_cast<Opt *>(p.optbuf) + c;
-    *dst = o;
-    KLHR_FB(p, F_PASS, c) = (double)npass;
-}
-__device__ __forceinline__ void opt_restore(const KParams &p, long long c, Opt &o) { o = *(reinterpret_cast<const Opt *>(p.optbuf) + c); }
+// The fit kernel for many chains: lane = chain (64 chains per wavefront, static), both stages of fit() one after the other in
+// ONE launch (klhr_fit12_kernel): the 1-D mode search with opt_advance<N = 1>, then the KL fit with opt_advance<N = 4 | 3 | 2>;
+// a lane's stage 2 reads back what its stage 1 wrote.  Every chain runs to completion (safety valve: KLHR_MAX_PASSES).
+// (Measured and removed in round 3, see DESIGN.md "dead ends": asynchronous chains with pass budgets, handing the long tail of
+//  the KL fits to a node-parallel resume kernel, fewer chains per fit wavefront — none of them gained beside the chain groups.)
 
 // Stage 1 of fit(): minimize(logp_grad_rho, x0, BFGS, gtol = 1e-5) (klhr_sinh.py:183-190)
 template <int MODEL>
 __device__ __forceinline__ void fit1_body(const KParams &p) {
-    const int lane = threadIdx.x & 63;
-    if (p.resume_budget && blockIdx.x == 0 && threadIdx.x == 0) *p.resume_count = 0;      // (the KL fit of this round fills the list)
-    const long long task = (long long)blockIdx.x * p.fit_lanes + lane;
-    if (lane >= p.fit_lanes || task >= p.C) return;
+    const long long task = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
+    if (task >= p.C) return;
     const bool diag = (p.flags & FLAG_DIAG) != 0;
-    int ph = p.async_mode ? p.phase[task] : PHS_FIT1;
-    if (ph != PHS_FIT1 && ph != PHS_FIT1_RESUME) return;
     Opt o;
     const LineStat st = load_stat(p, task);
     int npass = 0;
-    if (ph == PHS_FIT1_RESUME) { opt_restore(p, task, o); npass = (int)KLHR_FB(p, F_PASS, task); }
-    else {
+    {
         const double x0v[4] = {KLHR_FB(p, F_X0, task), 0, 0, 0};
         if (diag) p.d_diag[task * KLHR_NDIAG + KLHR_D_X0] = x0v[0];
         opt_begin(o, 1, x0v, 1e-5);
     }
-    const int budget = p.async_mode ? p.budget1 : KLHR_MAX_PASSES;
     bool live = true;
-    int ltrips = 0;
     while (__any(live)) {
         if (live) {
             double f = 0, g[4] = {0, 0, 0, 0};
@@ -235,7 +222,6 @@ __device__ __forceinline__ void fit1_body(const KParams &p) {
                 npass++;
             }
             opt_advance<false, 1>(o, f, g);
-            ++ltrips;
             const bool capped = npass > KLHR_MAX_PASSES;            // safety valve (klhr_kernels.hpp)
             if (o.pc == PC_DONE || capped) {
                 double s = o.H[0];
@@ -250,38 +236,25 @@ __device__ __forceinline__ void fit1_body(const KParams &p) {
                     dd[KLHR_D_MODE] = o.xk[0]; dd[KLHR_D_HINV1] = o.H[0]; dd[KLHR_D_NFEV1] = o.nfev; dd[KLHR_D_NIT1] = o.k;
                     dd[KLHR_D_STATUS1] = o.status; dd[KLHR_D_FALLBACKS] = o.fallbacks;
                 }
-                ph = PHS_FIT2;
-                live = false;
-            } else if (ltrips >= budget) {
-                opt_save(p, task, o, npass);
-                ph = PHS_FIT1_RESUME;
                 live = false;
             }
         }
     }
-    if (p.async_mode) p.phase[task] = ph;
 }
-
-template <int MODEL>
-__global__ __launch_bounds__(64) void klhr_fit1_kernel(const KParams p) { fit1_body<MODEL>(p); }
 
 // Stage 2 of fit(): minimize(KL, init, BFGS, gtol = 1e-3) (klhr_sinh.py:191-201; klhr.py:134-139; sub_klhr_sinh.py:184-192)
 template <int MODEL, int VARIANT>
 __device__ __forceinline__ void fit2_body(const KParams &p) {
     constexpr int N = VARIANT == VAR_GAUSS ? 2 : (VARIANT == VAR_SUB ? 3 : 4);
-    const int lane = threadIdx.x & 63;
-    const long long task = (long long)blockIdx.x * p.fit_lanes + lane;
-    if (lane >= p.fit_lanes || task >= p.C) return;
+    const long long task = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
+    if (task >= p.C) return;
     const bool diag = (p.flags & FLAG_DIAG) != 0;
-    int ph = p.async_mode ? p.phase[task] : PHS_FIT2;
-    if (ph != PHS_FIT2 && ph != PHS_FIT2_RESUME) return;
     Opt o;
     const LineStat st = load_stat(p, task);
     const double nn = KLHR_FB(p, F_NN, task);
-    int npass = 0, npass1 = 0;
-    if (ph == PHS_FIT2_RESUME) { opt_restore(p, task, o); npass = (int)KLHR_FB(p, F_PASS, task); }
-    else {
-        npass1 = (int)KLHR_FB(p, F_PASS, task);
+    int npass = 0;
+    const int npass1 = (int)KLHR_FB(p, F_PASS, task);
+    {
         const double init[4] = {KLHR_FB(p, F_MODE, task), KLHR_FB(p, F_INIT1, task),
                                 VARIANT == VAR_GAUSS ? 0.0 : KLHR_FB(p, F_N2, task),
                                 VARIANT == VAR_SINH ? KLHR_FB(p, F_N3, task) : 0.0};
@@ -291,10 +264,7 @@ __device__ __forceinline__ void fit2_body(const KParams &p) {
         }
         opt_begin(o, N, init, VARIANT == VAR_GAUSS ? 1e-5 : 1e-3);
     }
-    const bool hand_over = !p.async_mode && p.resume_budget > 0;
-    const int budget = p.async_mode ? p.budget2 : (hand_over ? p.resume_budget : KLHR_MAX_PASSES);
     bool live = true;
-    int ltrips = 0;
     while (__any(live)) {
         if (live) {
             double f = 0, g[4] = {0, 0, 0, 0};
@@ -308,7 +278,6 @@ __device__ __forceinline__ void fit2_body(const KParams &p) {
                 npass++;
             }
             opt_advance<false, N>(o, f, g);
-            ++ltrips;
             const bool capped = npass > KLHR_MAX_PASSES;
             if (o.pc == PC_DONE || capped) {
 #pragma unroll
@@ -320,25 +289,11 @@ __device__ __forceinline__ void fit2_body(const KParams &p) {
                     dd[KLHR_D_NFEV2] = o.nfev; dd[KLHR_D_NIT2] = o.k; dd[KLHR_D_STATUS2] = o.status; dd[KLHR_D_FUN2] = o.old_fval;
                     dd[KLHR_D_FALLBACKS] += o.fallbacks; dd[KLHR_D_PASSES] = npass1 + npass;       // (diagnostic launches only)
                 }
-                ph = PHS_TAIL;
-                live = false;
-            } else if (ltrips >= budget) {
-                opt_save(p, task, o, npass);
-                if (hand_over) {          // (a few per cent of the chains: plain atomics)
-                    KLHR_FB(p, F_PASS1, task) = (double)npass1;
-                    p.resume_list[atomicAdd(p.resume_count, 1u)] = (int)task;
-                }
-                ph = PHS_FIT2_RESUME;
                 live = false;
             }
         }
     }
-    if (p.async_mode) p.phase[task] = ph;
 }
-template <int MODEL, int VARIANT>
-__global__ __launch_bounds__(64) void klhr_fit2_kernel(const KParams p) { fit2_body<MODEL, VARIANT>(p); }
-// Both stages, lane = chain, in one launch (the synchronous rounds with many chains): one launch and one launch tail less per
-// iteration; a lane's stage 2 reads back what its stage 1 wrote.  The bodies are the two kernels' own.
 template <int MODEL, int VARIANT>
 __global__ __launch_bounds__(64) void klhr_fit12_kernel(const KParams p) {
     fit1_body<MODEL>(p);
@@ -492,63 +447,11 @@ __global__ __launch_bounds__(64) void klhr_fitn_kernel(const KParams p) {
     fitn_body<MODEL, VARIANT>(p, (long long)blockIdx.x * 8 + (lane >> 3), lane & 7);
 }
 
-// The KL fits that klhr_fit2_kernel handed over (KParams::resume_budget): node-parallel from the saved optimiser state on.
-// The distribution of a fit's passes is narrow with a thin long tail (funnel-100: median 13, 90 % <= 14, 1 % >= 28, rare 60-75):
-// lane = chain, one such chain holds its 63 neighbours' lanes idle and the launch lasts as long as the slowest chain; here
-// the tail runs 8 lanes per chain (a third of the latency per pass) on its own few wavefronts.  Same arithmetic per pass as
-// klhr_fit2_kernel: where a fit is finished shows in no bit of the result.
-template <int MODEL, int VARIANT>
-__global__ __launch_bounds__(64) void klhr_fit2r_kernel(const KParams p) {
-    constexpr int N = VARIANT == VAR_GAUSS ? 2 : (VARIANT == VAR_SUB ? 3 : 4);
-    const int lane = threadIdx.x & 63, l8 = lane & 7;
-    const bool diag = (p.flags & FLAG_DIAG) != 0, lead = l8 == 0;
-    const unsigned int count = *p.resume_count;
-    double q_a = p.asx[0], q_x = p.xq[0], q_w = p.wq[0];
-#pragma unroll
-    for (int n = 1; n < 8; n++) if (l8 == n) { q_a = p.asx[n]; q_x = p.xq[n]; q_w = p.wq[n]; }
-    for (unsigned int first = blockIdx.x * 8u; first < count; first += gridDim.x * 8u) {       // (wave-uniform bounds)
-        const unsigned int item = first + (unsigned int)(lane >> 3);
-        if (item < count) {                     // (whole octets: the butterflies stay inside an octet)
-            const long long task = p.resume_list[item];
-            const LineStat st = load_stat(p, task);
-            const double nn = KLHR_FB(p, F_NN, task);
-            Opt o;
-            opt_restore(p, task, o);
-            int npass = (int)KLHR_FB(p, F_PASS, task);
-            const int npass1 = (int)KLHR_FB(p, F_PASS1, task);
-            bool live = true;
-            while (__any(live)) {
-                if (live) {
-                    double f = 0, g[4] = {0, 0, 0, 0};
-                    if (opt_cache_hit(o)) { f = o.lf; g[0] = o.lg[0]; g[1] = o.lg[1]; g[2] = o.lg[2]; g[3] = o.lg[3]; }
-                    else {
-                        node_eval_kl<MODEL, VARIANT>(p, st, task, nn, o.xt, q_a, q_x, q_w, f, g);
-                        opt_cache_store(o, f, g);
-                        npass++;
-                    }
-                    opt_advance<false, N>(o, f, g);
-                    if (o.pc == PC_DONE || npass > KLHR_MAX_PASSES) live = false;
-                }
-            }
-            if (l8 < 4) p.d_eta[task * 4 + l8] = l8 == 0 ? o.xk[0] : (l8 == 1 ? o.xk[1] : (l8 == 2 ? o.xk[2] : o.xk[3]));
-            if (lead) {
-                KLHR_FB(p, F_NFEV2, task) = (double)o.nfev;
-                if (o.pc != PC_DONE) atomicOr(&p.status[task], 8);
-                if (diag) {
-                    double *dd = p.d_diag + task * KLHR_NDIAG;
-                    dd[KLHR_D_NFEV2] = o.nfev; dd[KLHR_D_NIT2] = o.k; dd[KLHR_D_STATUS2] = o.status; dd[KLHR_D_FUN2] = o.old_fval;
-                    dd[KLHR_D_FALLBACKS] += o.fallbacks; dd[KLHR_D_PASSES] = npass1 + npass;
-                }
-            }
-        }
-    }
-}
-
 // KL / line probes of the C ABI (klhr_kl_eval, klhr_line_eval): one evaluation per chain at eta = d_eta
 template <int MODEL, int VARIANT>
 __global__ __launch_bounds__(64) void klhr_probe_kernel(const KParams p) {
-    const long long c = (long long)blockIdx.x * p.fit_lanes + (threadIdx.x & 63);
-    if ((int)(threadIdx.x & 63) >= p.fit_lanes || c >= p.C) return;
+    const long long c = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
+    if (c >= p.C) return;
     const LineStat st = load_stat(p, c);
     const double nn = KLHR_FB(p, F_NN, c);
     double eta[4], f = 0, g[4] = {0, 0, 0, 0};
@@ -803,20 +706,7 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
     }
     // (a wavefront whose tile lies beyond the last chain ends here; s_barrier waits for the surviving wavefronts only)
     if (lane >= W || c >= p.C) return;
-    // async mode: a chain takes part in this launch with the tail of its finished fit (PHS_TAIL) and / or the head of its
-    // next iteration (PHS_HEAD, while it has draws to go); chains in the middle of a fit sit the launch out
-    int ph = PHS_HEAD;
-    bool run_tail = do_tail != 0, run_head = do_head != 0;
-    if (p.async_mode) {
-        ph = p.phase[c];
-        run_tail = ph == PHS_TAIL;
-        const bool mid_fit = ph != PHS_TAIL && ph != PHS_HEAD;
-        const bool more = p.togo[c] - (run_tail ? 1 : 0) > 0;                         // draws still to go after this launch's tail
-        run_head = !mid_fit && more;
-        const unsigned long long busy = __ballot(mid_fit || run_head);               // chains with work left after this launch
-        if (busy && lane == (int)(__ffsll((long long)busy) - 1)) atomicAdd(p.pend, (unsigned int)__popcll(busy));
-        if (mid_fit || (!run_tail && !run_head)) return;
-    }
+    const bool run_tail = do_tail != 0, run_head = do_head != 0;
     const long long tb = tile * D * W + lane;
     const long long tbe = tile * D * nc * W + lane;
     const long long tbv = tile * D * K * W + lane;
@@ -897,10 +787,7 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
     }
     double u_choice = 0.0, ssq = 0.0;
     if (tail_here) {
-        // recorded draws: slot = the chain's own draw index within this call (chains may be rounds apart in async mode)
-        long long slot = (long long)draw_slot;
-        if (p.async_mode) { const int tg = p.togo[c]; slot = (long long)p.n_iters - tg; p.togo[c] = tg - 1; }
-        double *out = p.draws ? p.draws + slot * p.draw_stride + c * D : nullptr;
+        double *out = p.draws ? p.draws + (long long)draw_slot * p.draw_stride + c * D : nullptr;
         // ---- pass T1: theta' = a (theta + zp rho) + (1 - a) theta; OnlineMoments(theta'); Z = theta' - mean
         double d2 = 0.0;
         bool fin = true;
@@ -1113,7 +1000,6 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
     }
 
     // ---- store the per-chain scalars (pair mode: the RNG state by the head's wavefront, the rest by the tail's)
-    if (p.async_mode) p.phase[c] = run_head ? PHS_FIT1 : PHS_HEAD;
     if (role != 0) { p.rng[c * 4 + 0] = rng.sh; p.rng[c * 4 + 1] = rng.sl; p.rng[c * 4 + 2] = rng.ih; p.rng[c * 4 + 3] = rng.il; }
     if (role != 1) {
         p.counters[c * 4 + 0] = draw; p.counters[c * 4 + 1] = omN; p.counters[c * 4 + 2] = pcan; p.counters[c * 4 + 3] = cidx;

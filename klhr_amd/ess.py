@@ -18,14 +18,18 @@ def _autocov(x):
     return ac / M
 
 
-def ess(x):
-    """x: (M, C) draws of one scalar for C chains -> total effective sample size (float)."""
+def ess_detail(x):
+    """x: (M, C) draws of one scalar for C chains -> dict with the total effective sample size `ess`, the integrated
+    autocorrelation time `tau` (draws per effective draw, of the combined estimate), the lag `truncation_lag` at which
+    Geyer's initial-positive sequence ended (== M means it never did: the estimate is then bounded by the window, not by
+    the chain, and must not be quoted), and the split-free potential scale reduction `rhat` (sqrt(var_plus / W))."""
     x = np.asarray(x, dtype=np.float64)
     if x.ndim == 1:
         x = x[:, None]
     M, C = x.shape
+    nan = float("nan")
     if M < 4:
-        return float("nan")
+        return {"ess": nan, "tau": nan, "truncation_lag": M, "rhat": nan, "draws": M, "chains": C}
     acov = _autocov(x)
     chain_var = acov[0] * M / (M - 1.0)
     W = chain_var.mean()
@@ -33,7 +37,7 @@ def ess(x):
     if C > 1:
         var_plus += x.mean(axis=0).var(ddof=1)
     if not np.isfinite(var_plus) or var_plus <= 0:
-        return float("nan")
+        return {"ess": nan, "tau": nan, "truncation_lag": M, "rhat": nan, "draws": M, "chains": C}
     rho = 1.0 - (W - acov.mean(axis=1)) / var_plus
     rho[0] = 1.0
     # Geyer: sums of adjacent pairs must be positive and non-increasing
@@ -48,8 +52,15 @@ def ess(x):
         prev = pair
         tau += 2.0 * pair
         t += 2
+    lag = t if t + 1 < M else M
     tau = max(tau, 1.0 / np.log10(max(M * C, 10)))
-    return float(M * C / tau)
+    return {"ess": float(M * C / tau), "tau": float(tau), "truncation_lag": int(lag), "rhat": float(np.sqrt(var_plus / W)) if W > 0 else nan,
+            "draws": M, "chains": C}
+
+
+def ess(x):
+    """x: (M, C) draws of one scalar for C chains -> total effective sample size (float)."""
+    return ess_detail(x)["ess"]
 
 
 def ess_ar1_exact(M, phi):

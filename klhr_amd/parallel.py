@@ -1,14 +1,18 @@
-"""Multi-GPU layer: chains shard across the GPUs of a node, one process per GPU (torch.distributed rendezvous).
+"""Multi-GPU layer: chains shard across the GPUs of a node, one process per GPU.
 
 Parity mode (default) has NO data-path collective: every chain owns its RNG and its own adaptation state, exactly as
 one reference process per chain would (run_experiments:27 fans out with GNU parallel).  The optional pooled-adaptation
-mode (an extension; NOT reference behaviour) all-reduces, at window closures only, the sufficient
-statistics [n, sum theta, sum theta^2] (1 + 2D doubles: latency-bound over xGMI) and overwrites every chain's
-direction mean / diagonal covariance with the pooled values.  pooled="full" (the north-star's "pool the covariance across shards") keeps everything on the device and inside the library:
-LDS-tiled MFMA Gram of the window's draws -> ONE ncclAllReduce (RCCL over xGMI) of 1 + D + D^2 doubles on the handle's
-stream (klhr_comm_init / klhr_pool_allreduce, include/klhr.h) -> one D2H copy -> eigen-decomposition on every rank.  No
-PyTorch on that path; torch.distributed (gloo) is only the host channel that hands the communicator id to the ranks, and
-the stand-in collective of the CPU tests.
+modes (an extension; NOT reference behaviour) pool, at window closures only, the window's draws of all chains of
+all ranks: LDS-tiled MFMA Gram of the window's draws on every GPU -> ONE ncclAllReduce (RCCL over xGMI) of 1 + D + D^2 doubles on
+the handle's stream (klhr_comm_init / klhr_pool_allreduce, include/klhr.h) -> one D2H copy -> every rank derives the same pooled
+values: pooled="full" installs mean, covariance diagonal and the top eigenpairs (the north-star's "pool the covariance across
+shards"), pooled="diag" mean and per-coordinate variance only.
+
+This module imports neither PyTorch nor any other collective library: the collective is RCCL inside libklhr_hip.so.  A host
+channel is needed once, to hand rank 0's 128-byte communicator id to the other ranks — any object with
+`broadcast_object_list` (torch.distributed's gloo group in bench.py) or a file (KLHR_COMM_FILE).  Where RCCL cannot run —
+CPU tests, rehearsals whose ranks share one GPU (RCCL wants one device per rank) — the caller injects `host_allreduce`, a
+function summing a small fp64 vector over the ranks, as a stand-in.
 """
 import os
 
@@ -31,18 +35,6 @@ def shard_seeds(base_seed, n_total, rank, world):
     and every chain's trajectory — is independent of how many GPUs the job runs on."""
     lo, hi = shard_range(n_total, rank, world)
     return (np.uint64(base_seed) + np.arange(lo, hi, dtype=np.uint64)).astype(np.uint64)
-
-
-def allreduce_sum(vec, dist=None, device=None):
-    """Sum a small fp64 host vector over all ranks (RCCL when the process group is nccl, else gloo)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return np.array(vec, dtype=np.float64)
-    import torch
-    t = torch.from_numpy(np.array(vec, dtype=np.float64))
-    if dist.get_backend() == "nccl":
-        t = t.to(f"cuda:{device if device is not None else torch.cuda.current_device()}")
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return t.cpu().numpy()
 
 
 def pooled_moments(stats):
@@ -77,9 +69,18 @@ def pooled_full(stats, D, ncol):
     return mean, np.maximum(np.diag(S), 0.0), np.ascontiguousarray(vecs), vals
 
 
+def one_device_per_rank():
+    """True when every rank of this node has a GPU of its own (LOCAL_WORLD_SIZE <= visible devices): what RCCL needs."""
+    from . import _lib
+    _, world, _ = dist_env()
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    return local_world <= max(1, _lib.device_count())
+
+
 def exchange_comm_id(rank, world, dist=None):
-    """The 128-byte RCCL communicator id of rank 0 on every rank.  Host plumbing only: torch.distributed (gloo) when a process
-    group is given, else a file named by KLHR_COMM_FILE (rank 0 writes it, the others wait for it)."""
+    """The 128-byte RCCL communicator id of rank 0 on every rank.  Host plumbing only: `dist.broadcast_object_list` when a
+    process group object is given, else a file named by KLHR_COMM_FILE + the job's MASTER_PORT (rank 0 removes a stale file of
+    an earlier run before anything else and writes it atomically; the others wait for a file newer than their own start)."""
     from . import _lib
     if world == 1:
         return _lib.comm_unique_id()
@@ -89,30 +90,44 @@ def exchange_comm_id(rank, world, dist=None):
         return box[0]
     path = os.environ.get("KLHR_COMM_FILE")
     if not path:
-        raise RuntimeError("exchange_comm_id: need a torch.distributed process group or KLHR_COMM_FILE")
+        raise RuntimeError("exchange_comm_id: need a process group with broadcast_object_list or KLHR_COMM_FILE")
+    import time
+    path = f"{path}.{os.environ.get('MASTER_PORT', '0')}"
+    t_start = time.time()
     if rank == 0:
+        try:
+            os.unlink(path)                     # a stale id of an earlier run would hang the other ranks in ncclCommInitRank
+        except FileNotFoundError:
+            pass
         with open(path + ".tmp", "wb") as f:
             f.write(_lib.comm_unique_id())
         os.replace(path + ".tmp", path)
-    import time
     for _ in range(6000):
-        if os.path.exists(path):
-            return open(path, "rb").read()
+        try:
+            if os.path.getmtime(path) >= t_start - 1.0:
+                data = open(path, "rb").read()
+                if len(data) == 128:
+                    return data
+        except OSError:
+            pass
         time.sleep(0.01)
     raise RuntimeError("exchange_comm_id: timed out waiting for " + path)
 
 
-def pooled_setup_draws(s, n, rank, world, dist, mode="full", warmup=100, windowsize=50, windowscale=2, segment=50):
-    """bench.py --pooled: run `n` draws on the raw sampler `s` with pooled adaptation at the window closures, the collective
-    inside the library (RCCL).  Returns what was done, with the mean time of an all-reduce call measured on the host."""
+def pooled_setup_draws(s, n, rank, world, dist, mode="full", warmup=100, windowsize=50, windowscale=2, segment=50, host_allreduce=None):
+    """bench.py --pooled / its N > 1 config-5 shard: run `n` draws on the raw sampler `s` with pooled adaptation at the window
+    closures, the collective inside the library (RCCL).  Returns what was done, with the time of every all-reduce + fetch
+    measured on the host.  Ranks that share a GPU (rehearsals) cannot form an RCCL communicator: they sum through
+    `host_allreduce` and the returned record says so."""
     import time
     from . import _lib
     closures = _lib.window_closures(warmup, windowsize, windowscale)
     D, ncol = s.D, s.ncol
-    # RCCL wants one device per rank: a rehearsal with more ranks than GPUs (ranks sharing a device) sums on the host instead
-    use_rccl = world <= max(1, _lib.device_count())
+    use_rccl = world == 1 or one_device_per_rank()
     if use_rccl:
         s.comm_init(exchange_comm_id(rank, world, dist), rank, world)
+    elif host_allreduce is None:
+        raise RuntimeError("pooled_setup_draws: ranks share a device (no RCCL communicator possible) and no host_allreduce was given")
     done, times = 0, []
     s.pool_reset()
     while done < n:
@@ -134,7 +149,7 @@ def pooled_setup_draws(s, n, rank, world, dist, mode="full", warmup=100, windows
         s.pool_allreduce()
         tot = s.pool_fetch()
         if not use_rccl:
-            tot = allreduce_sum(tot, dist)
+            tot = host_allreduce(tot)
         times.append(time.perf_counter() - t0)
         s.step(1)                                  # the closure iteration (klhr_sinh.py:268-280)
         done += 1
@@ -143,60 +158,74 @@ def pooled_setup_draws(s, n, rank, world, dist, mode="full", warmup=100, windows
             if mode == "full":
                 s.pool_apply_full(*pooled_full(tot, D, ncol))
             else:
-                mean = tot[1:1 + D] / tot[0]
-                var = (np.diag(tot[1 + D:].reshape(D, D)) / tot[0] - mean * mean) * tot[0] / max(tot[0] - 1.0, 1.0)
-                s.pool_apply(mean, np.maximum(var, 0.0))
-    return {"mode": mode, "ranks": world,
+                s.pool_apply(*pooled_diag(tot, D))
+    return {"mode": mode, "ranks": world, "comm_world": s.comm_world(), "one_device_per_rank": bool(use_rccl),
             "collective": "ncclAllReduce (RCCL) on the handle's stream, inside libklhr_hip.so" if use_rccl else
-                          "host sum over gloo (rehearsal: ranks share a GPU, RCCL needs one device per rank)",
+                          "host sum (rehearsal: ranks share a GPU, RCCL needs one device per rank)",
             "doubles_per_allreduce": 1 + D + D * D, "closures_pooled": len(times),
             "allreduce_plus_fetch_ms": [t * 1e3 for t in times]}
+
+
+def pooled_diag(stats, D):
+    """[n, sum x (D), sum x x^T (D*D)] -> pooled mean and unbiased per-coordinate variance (the diagonal of pooled_full's matrix)"""
+    stats = np.asarray(stats, dtype=np.float64)
+    n = stats[0]
+    mean = stats[1:1 + D] / n
+    var = (np.diag(stats[1 + D:].reshape(D, D)) / n - mean * mean) * n / max(n - 1.0, 1.0)
+    return mean, np.maximum(var, 0.0)
 
 
 class ShardedKLHRSINH:
     """All chains of a multi-GPU job behind one object; every rank constructs it with the same arguments."""
 
-    SEGMENT = 50        # pooled="full": draws of at most this many iterations are kept on the device at a time
+    SEGMENT = 50        # pooled modes: draws of at most this many iterations are kept on the device at a time
 
-    def __init__(self, bsmodel, chains_total, seed=0, pooled=False, dist=None, rccl=None, **kw):
+    def __init__(self, bsmodel, chains_total, seed=0, pooled=False, dist=None, rccl=None, host_allreduce=None, **kw):
         """pooled: False (parity mode, no collective) | True / "diag" (pool mean + per-coordinate variance) |
-        "full" (pool the full covariance: fp64 MFMA Gram of the window's draws per GPU, one all-reduce of
-        1 + D + D^2 doubles per window closure, eigen-decomposition on every rank).
-        rccl: pooled="full" only — True: the all-reduce is ncclAllReduce inside the library (default when the process group
-        is not gloo-on-CPU-tensors only, i.e. on a multi-GPU node); False: the statistics are fetched and summed through
-        `dist` (gloo) on the host — the stand-in used by the CPU tests and by rehearsals where ranks share one GPU."""
+        "full" (pool the full covariance: mean, diagonal, top eigenpairs).  Both pooled modes take the window's statistics from
+        the fp64 MFMA Gram of its draws per GPU and ONE all-reduce of 1 + D + D^2 doubles per window closure.
+        rccl: None (default) = the all-reduce is ncclAllReduce inside the library whenever there is more than one rank and
+        every rank has its own device; True forces a communicator (also with one rank: the 1-GPU test of that path); False
+        never creates one.  Without a communicator and with more than one rank, `host_allreduce(vec) -> summed vec` (the
+        caller's stand-in: CPU tests, rehearsals whose ranks share a GPU) is required.
+        dist: only handed to exchange_comm_id (broadcast_object_list) — no collective runs through it."""
         from .klhr_sinh import KLHRSINH
         self.rank, self.world, self.local_rank = dist_env()
         from . import _lib
         self.local_rank = self.local_rank % max(1, _lib.device_count())      # more ranks than GPUs (rehearsals): share devices
         self.dist = dist
-        self.pooled = pooled
+        self.pooled = "diag" if pooled is True else pooled
         lo, hi = shard_range(chains_total, self.rank, self.world)
         self.lo, self.hi = lo, hi
         self.local = KLHRSINH(bsmodel, seed=shard_seeds(seed, chains_total, self.rank, self.world), chains=hi - lo,
                               device=self.local_rank, overrelaxed=False, **kw)
         self._closures = list(self.local._windowedadaptation._closures)
         self._done = 0
-        self._full = pooled == "full"
-        self._rccl = bool(rccl) and self._full
+        self._full = self.pooled == "full"
+        if rccl is None:
+            rccl = bool(self.pooled) and self.world > 1 and one_device_per_rank()
+        self._rccl = bool(rccl) and bool(self.pooled)
+        self._host_allreduce = host_allreduce
+        if self.pooled and not self._rccl and self.world > 1 and host_allreduce is None:
+            raise RuntimeError("ShardedKLHRSINH: pooled adaptation over several ranks needs RCCL (one device per rank) or host_allreduce")
         if self._rccl:
             self.local._sampler.comm_init(exchange_comm_id(self.rank, self.world, dist), self.rank, self.world)
-        if self._full:
+        if self.pooled:
             self.local._sampler.pool_reset()
 
     def advance(self, n, record=False):
         """n iterations on this rank's shard.  Pooled mode stops in front of each window closure, all-reduces the
-        closing window's statistics, lets the closure iteration run, then overwrites mean/cov with the pooled values."""
+        closing window's statistics, lets the closure iteration run, then overwrites the direction state with the pooled values."""
         s = self.local._sampler
         out = []
 
         def run(k, accumulate=True):
             while k > 0:
-                kk = min(k, self.SEGMENT) if self._full else k
-                s.step(kk, record_draws=record or self._full)
+                kk = min(k, self.SEGMENT) if self.pooled else k
+                s.step(kk, record_draws=record or bool(self.pooled))
                 if record:
                     out.append(s.draws(0, kk))
-                if self._full and accumulate:          # statistics of the open window (the closure draw is excluded):
+                if self.pooled and accumulate:         # statistics of the open window (the closure draw is excluded):
                     s.pool_accumulate(0, kk)           # device-resident, no copy
                 self._done += kk
                 k -= kk
@@ -205,7 +234,7 @@ class ShardedKLHRSINH:
         while left > 0:
             nxt = next((c for c in self._closures if c > self._done), None) if self.pooled else None
             if nxt is None:
-                run(left)
+                run(left, accumulate=False)
                 break
             before = nxt - 1 - self._done
             if before > 0:
@@ -213,22 +242,17 @@ class ShardedKLHRSINH:
                 run(k)
                 left -= k
                 continue
-            if self._full:
-                D = self.local.D
-                s.pool_allreduce()                    # packs; with a communicator: ONE ncclAllReduce on the device
-                tot = s.pool_fetch()
-                if not self._rccl:
-                    tot = allreduce_sum(tot, self.dist, self.local_rank)       # host stand-in (gloo)
-                run(1, accumulate=False)              # the closure iteration (klhr_sinh.py:268-280)
-                left -= 1
-                s.pool_reset()
-                if tot[0] > 2 and np.isfinite(tot).all():
+            D = self.local.D
+            s.pool_allreduce()                    # packs; with a communicator: ONE ncclAllReduce on the device
+            tot = s.pool_fetch()
+            if not self._rccl and self.world > 1:
+                tot = self._host_allreduce(tot)    # stand-in (CPU tests, ranks sharing a GPU)
+            run(1, accumulate=False)              # the closure iteration (klhr_sinh.py:268-280)
+            left -= 1
+            s.pool_reset()
+            if tot[0] > 2 and np.isfinite(tot).all():
+                if self._full:
                     s.pool_apply_full(*pooled_full(tot, D, s.ncol))
-            else:
-                tot = allreduce_sum(s.pool_stats(), self.dist, self.local_rank)
-                run(1)                                # the closure iteration
-                left -= 1
-                if tot[0] > 2 and np.isfinite(tot).all():
-                    mean, var = pooled_moments(tot)
-                    s.pool_apply(mean, var)
+                else:
+                    s.pool_apply(*pooled_diag(tot, D))
         return np.concatenate(out) if record else None

@@ -328,16 +328,21 @@ TWO_RANK_WORKER = r'''
 import os, sys, json
 import numpy as np
 sys.path.insert(0, os.environ["KLHR_ROOT"])
+import torch
 import torch.distributed as dist
 from klhr_amd import BSModel
 from klhr_amd.parallel import ShardedKLHRSINH, dist_env
 rank, world, _ = dist_env()
 dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+def host_sum(vec):          # two ranks share the one GPU: RCCL cannot form a communicator, the caller injects the stand-in
+    t = torch.from_numpy(np.array(vec, dtype=np.float64))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.numpy()
 stan = os.path.join(os.environ["KLHR_ROOT"], "klhr_amd", "stan")
 m = BSModel(os.path.join(stan, "funnel.stan"), os.path.join(stan, "funnel.json"))
 out = {}
 for mode in (False, "diag", "full"):
-    sh = ShardedKLHRSINH(m, 96, seed=5, pooled=mode, dist=dist, warmup=100)
+    sh = ShardedKLHRSINH(m, 96, seed=5, pooled=mode, dist=dist, rccl=False, host_allreduce=host_sum, warmup=100)
     sh.advance(50)                                   # up to and including the first window closure
     s = sh.local._sampler
     first = {"mean50": s.get("mean").tolist(), "cov50": s.get("cov").tolist()}

@@ -684,32 +684,11 @@ def test_slice_free_running_and_python_class():
     assert abs(d.mean()) < 0.02 and abs(d.var() - 1.0) < 0.04
 
 
-def test_asynchronous_chains_equal_synchronous_rounds(monkeypatch, kernel_mode):
-    """KLHR_ASYNC=1 (split pipeline): fit launches are cut at a pass budget and unfinished fits resume in the next round, so
-    chains advance at their own pace — when a pass runs must not show in any result.  Tiny budgets force many carry-overs."""
-    if kernel_mode != "split":
-        pytest.skip("the asynchronous rounds belong to the split pipeline")
-    stem, data = model_spec("funnel10")
-    seeds = np.arange(200, dtype=np.uint64) + 900
-    out = []
-    for mode in ("0", "1"):
-        monkeypatch.setenv("KLHR_ASYNC", mode)
-        monkeypatch.setenv("KLHR_FIT_BUDGET1", "3")
-        monkeypatch.setenv("KLHR_FIT_BUDGET2", "5")
-        s = make_sampler(stem, data, 200, warmup=100)
-        s.seed(seeds)
-        s.step(60, record_draws=True)
-        s.step(3)
-        out.append((s.draws(0, 60), s.get("theta"), s.get("rng"), s.get("cov"), s.get("pca_v"), s.get("grad_evals"), s.get("acc"), s.get("counters")))
-    for a, b in zip(out[0], out[1]):
-        assert np.array_equal(a, b)
-
-
 @pytest.mark.parametrize("name", ["funnel100", "illnormal100", "funnel10", "ar1x100"])
 @pytest.mark.parametrize("variant,over", [(0, False), (0, True), (1, False), (2, False)])
 def test_node_parallel_fit_equals_lane_per_chain_fit(monkeypatch, kernel_mode, name, variant, over):
     """Split pipeline: up to 32 768 chains both stages of fit() run in klhr_fitn_kernel (8 lanes per chain, one quadrature
-    node per lane, butterfly sums with the lane form's tree), above that in klhr_fit1_kernel / klhr_fit2_kernel (lane = chain).
+    node per lane, butterfly sums with the lane form's tree), above that in klhr_fit12_kernel (lane = chain).
     Which one ran must not show in any bit of a chain's state — size independence (test_gpu_fullsize.py) rests on it.
     The small clip bounds make the exact element-wise patch of the closed form (rare at the defaults) a common path."""
     if kernel_mode != "split":
@@ -728,31 +707,6 @@ def test_node_parallel_fit_equals_lane_per_chain_fit(monkeypatch, kernel_mode, n
             assert ("fitn" in s.kernel_name()) == (mode == "1"), s.kernel_name()
             out.append([s.get(f) for f in ("theta", "rng", "cov", "eigvecs", "pca_v", "grad_evals", "acc", "counters", "diag", "status")])
         for a, b in zip(out[0], out[1]):
-            assert np.array_equal(a, b, equal_nan=True)
-
-
-@pytest.mark.parametrize("variant,over", [(0, False), (0, True), (1, False), (2, False)])
-def test_handed_over_fits_equal_fits_finished_in_place(monkeypatch, kernel_mode, variant, over):
-    """KLHR_FIT_RESUME=1 (split pipeline, lane = chain fit kernels): the KL fit stops at a pass budget and the unfinished fits
-    are finished by the node-parallel resume kernel from the saved optimiser state.  A budget of 3 hands over nearly every
-    fit, 14 the tail only; neither may show in any bit of a chain's state."""
-    if kernel_mode != "split":
-        pytest.skip("the fit kernels of the split pipeline")
-    stem, data = model_spec("funnel100")
-    C = 203
-    seeds = np.arange(C, dtype=np.uint64) + 7300
-    monkeypatch.setenv("KLHR_FITN", "0")
-    out = []
-    for resume, budget in (("0", "1"), ("1", "3"), ("1", "14")):
-        monkeypatch.setenv("KLHR_FIT_RESUME", resume)
-        monkeypatch.setenv("KLHR_FIT_RESUME_BUDGET", budget)
-        s = make_sampler(stem, data, C, warmup=100, variant=variant, overrelaxed=over)
-        s.seed(seeds)
-        s.step(70, record_diag=True)
-        assert ("fit2r" in s.kernel_name()) == (resume == "1"), s.kernel_name()
-        out.append([s.get(f) for f in ("theta", "rng", "cov", "eigvecs", "pca_v", "grad_evals", "acc", "counters", "diag", "status")])
-    for o in out[1:]:
-        for a, b in zip(out[0], o):
             assert np.array_equal(a, b, equal_nan=True)
 
 

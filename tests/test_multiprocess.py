@@ -14,8 +14,13 @@ import numpy as np
 sys.path.insert(0, os.environ["KLHR_ROOT"])
 import torch.distributed as dist
 from klhr_amd import parallel as P
+import torch
 rank, world, _ = P.dist_env()
 dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+def host_sum(vec):          # the stand-in collective a caller injects where RCCL cannot run (klhr_amd/parallel.py imports no torch)
+    t = torch.from_numpy(np.array(vec, dtype=np.float64))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.numpy()
 C_total, D = 37, 5
 lo, hi = P.shard_range(C_total, rank, world)
 seeds = P.shard_seeds(1000, C_total, rank, world)
@@ -24,17 +29,19 @@ rng = np.random.default_rng(7)
 X = rng.normal(size=(C_total, 11, D)) * np.arange(1, D + 1)
 mine = X[lo:hi]
 stats = np.concatenate([[mine.shape[0] * mine.shape[1]], mine.sum(axis=(0, 1)), (mine ** 2).sum(axis=(0, 1))])
-tot = P.allreduce_sum(stats, dist)
+tot = host_sum(stats)
 mean, var = P.pooled_moments(tot)
 flat = mine.reshape(-1, D)
 gram = np.concatenate([[flat.shape[0]], flat.sum(axis=0), (flat.T @ flat).reshape(-1)])
-fm, fdiag, fvec, fval = P.pooled_full(P.allreduce_sum(gram, dist), D, 2)
-t = P.allreduce_sum(np.array([float(rank + 1)]), dist)
+gtot = host_sum(gram)
+fm, fdiag, fvec, fval = P.pooled_full(gtot, D, 2)
+dm, dv = P.pooled_diag(gtot, D)
+t = host_sum(np.array([float(rank + 1)]))
 dist.barrier()
 with open(os.path.join(os.environ["KLHR_OUT"], f"result_{rank}.json"), "w") as f:
     json.dump({"rank": rank, "lo": lo, "hi": hi, "seeds": [int(s) for s in seeds], "mean": mean.tolist(),
                "var": var.tolist(), "sum": float(t[0]), "fm": fm.tolist(), "fdiag": fdiag.tolist(), "fvec": fvec.tolist(),
-               "fval": fval.tolist()}, f)
+               "fval": fval.tolist(), "dm": dm.tolist(), "dv": dv.tolist()}, f)
 dist.destroy_process_group()
 '''
 
@@ -60,9 +67,45 @@ def test_two_rank_gloo_sharding_and_pooling(tmp_path):
         S = np.cov(flat.T)
         w, V = np.linalg.eigh(S)
         assert np.allclose(r["fm"], flat.mean(axis=0), rtol=1e-12) and np.allclose(r["fdiag"], np.diag(S), rtol=1e-10)
+        assert np.allclose(r["dm"], flat.mean(axis=0), rtol=1e-12) and np.allclose(r["dv"], np.diag(S), rtol=1e-10)
         assert np.allclose(r["fval"], w[::-1][:2], rtol=1e-9)
         assert abs(abs(np.array(r["fvec"])[:, 0] @ V[:, -1]) - 1) < 1e-9
     assert res[0]["fvec"] == res[1]["fvec"]          # every rank derives bit-identical pooled directions
+
+
+def test_parallel_layer_imports_no_torch():
+    """north_star: "no PyTorch" on the product path — the multi-GPU layer's collective is RCCL inside the library; a host
+    stand-in is injected by the caller."""
+    src = open(os.path.join(ROOT, "klhr_amd", "parallel.py")).read()
+    assert "import torch" not in src
+    from klhr_amd import parallel as P
+    assert not hasattr(P, "allreduce_sum")
+
+
+def test_comm_id_file_exchange_ignores_a_stale_file(tmp_path, monkeypatch):
+    """exchange_comm_id over KLHR_COMM_FILE: a file left by an earlier run is never handed out (ranks > 0 wait for a fresh one)."""
+    import time
+    from klhr_amd import parallel as P
+    base = str(tmp_path / "id")
+    monkeypatch.setenv("KLHR_COMM_FILE", base)
+    monkeypatch.setenv("MASTER_PORT", "4711")
+    stale = base + ".4711"
+    open(stale, "wb").write(b"x" * 128)
+    os.utime(stale, (time.time() - 100, time.time() - 100))
+    import threading
+    got = {}
+
+    def reader():
+        got["id"] = P.exchange_comm_id(1, 2, None)
+    t = threading.Thread(target=reader)
+    t.start()
+    time.sleep(0.3)
+    assert "id" not in got                      # the stale file was not accepted
+    fresh = bytes(range(128))
+    open(stale + ".tmp", "wb").write(fresh)
+    os.replace(stale + ".tmp", stale)
+    t.join(timeout=10)
+    assert got.get("id") == fresh
 
 
 def test_shard_ranges_cover_everything():

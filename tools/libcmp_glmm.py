@@ -1,5 +1,5 @@
 """theta / rng / grad_evals of glmm-poisson-45 after N draws, saved to a file (arg 1) — run once per library (KLHR_LIB) and compare:
-python tools/dbg_libcmp_glmm.py out.npz [C] [N]; python tools/dbg_libcmp_glmm.py --cmp a.npz b.npz"""
+python tools/libcmp_glmm.py out.npz [C] [N]; python tools/libcmp_glmm.py --cmp a.npz b.npz"""
 import sys, os, json
 import numpy as np
 ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,ROOT)

@@ -1,5 +1,5 @@
 """Distribution of the fit's passes per chain-iteration (objective evaluations: nfev1 mode search, nfev2 KL fit) and how much of a
-launch the slowest chain of a wavefront / of the launch adds: python tools/dbg_passdist.py model D C"""
+launch the slowest chain of a wavefront / of the launch adds: python tools/pass_dist.py model D C"""
 import sys, os
 ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,ROOT)
 import numpy as np

@@ -5,12 +5,17 @@ profiles/traffic.json[<key>] with the HBM bytes per launch of the dominant kerne
 
 Corrections (MI355X_MICROARCH.md, HBM: calibrate on a known byte count in your own access pattern; tools/ubench/rowcal.hip,
 profiles/r02_calibration/rowcal.csv): FETCH_SIZE reports 0.500x the bytes of the split pipeline's tiled reads (8 B per lane,
-512-B or 128-B contiguous segments: double it) and 1.383-1.455x those of lane-private 8-byte row reads (monolithic kernels:
-divide); WRITE_SIZE 1.000x / 1.002x."""
+512-B or 128-B contiguous segments: double it) and 1.40x those of lane-private 8-byte row reads at D = 10 (monolithic
+kernels: divide; three runs of the same microbenchmark gave 1.3832 (profiles/r01b), 1.4547 (r02_calibration) and 1.3565
+(r03_calibration): the factor moves by +-3.5 % between runs, their mean is used); WRITE_SIZE 1.000x (tiled) / 1.003x (rows).
+
+Every entry carries `build_id` = klhr_build_id() of the library the bench line was produced with (bench.py prints it): bench.py
+quotes an entry only while the loaded library is that build.  The entry also carries the counter-derived fp64 rate of the
+dominant kernel: (2 FMA + ADD + MUL + TRANS) fp64 instructions x 64 lanes x the lanes-active share, per launch."""
 import csv, glob, json, os, shutil, sys, collections
 tag, key = sys.argv[1], sys.argv[2]
 cal = sys.argv[3] if len(sys.argv) > 3 else "tiled"
-FETCH_FACTOR = {"tiled": 0.5, "row": 1.383}[cal]
+FETCH_FACTOR = {"tiled": 0.5, "row": 1.40}[cal]
 out = f"profiles/{tag}"
 os.makedirs(out, exist_ok=True)
 base = f"gpurun_out/cfg_{tag}"
@@ -58,13 +63,28 @@ fetch_raw = sum(tail(d["FETCH_SIZE"])) / len(tail(d["FETCH_SIZE"])) * 1024
 write = sum(tail(d["WRITE_SIZE"])) / len(tail(d["WRITE_SIZE"])) * 1024
 fetch = fetch_raw / FETCH_FACTOR
 bench = json.loads([l for l in open(base + "_kt.log") if l.startswith("{")][-1])
+if not bench.get("build_id"):
+    raise SystemExit("the bench line carries no build_id: profile with a bench.py / library that reports klhr_build_id()")
 ipl = bench["roofline"].get("iters_per_launch") or bench["steps"] / max(1, bench["roofline"].get("launches", 1))
+sq = {c: sum(tail(v)) / len(tail(v)) for c, v in agg[dom].items()}
+lanes_active = sq["SQ_THREAD_CYCLES_VALU"] / (sq["SQ_ACTIVE_INST_VALU"] * 64)
+fp64_insts = 2 * sq["SQ_INSTS_VALU_FMA_F64"] + sq["SQ_INSTS_VALU_ADD_F64"] + sq["SQ_INSTS_VALU_MUL_F64"] + sq["SQ_INSTS_VALU_TRANS_F64"]
 tj_path = "profiles/traffic.json"
 tj = json.load(open(tj_path)) if os.path.exists(tj_path) else {}
-tj[key] = {"kernel": dom, "hbm_bytes_per_launch": fetch + write, "fetch_bytes_calibrated": fetch, "fetch_bytes_raw": fetch_raw, "write_bytes": write,
+tj[key] = {"kernel": dom, "build_id": bench["build_id"], "profile_dir": f"profiles/{tag}",
+           "hbm_bytes_per_launch": fetch + write, "fetch_bytes_calibrated": fetch, "fetch_bytes_raw": fetch_raw, "write_bytes": write,
            "iters_per_launch": ipl, "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_chain_iter"] * bench["config"]["chains_per_gpu"] * ipl,
            "source": f"profiles/{tag}/pmc_fetch_write.csv (mean of the last third of the dispatches); FETCH_SIZE / {FETCH_FACTOR}: calibration of the "
-                     f"{'tiled 8-byte coalesced' if cal == 'tiled' else 'lane-private row'} read pattern, profiles/r02_calibration/rowcal.csv"}
+                     f"{'tiled 8-byte coalesced' if cal == 'tiled' else 'lane-private row'} read pattern, profiles/r0{1b,2_calibration,3_calibration}/rowcal.csv",
+           "fp64_flops_per_launch": fp64_insts * 64 * lanes_active, "lanes_active": lanes_active,
+           "valu_active": sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"], "waiting": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"],
+           "valu_per_wavefront_iter": sq["SQ_INSTS_VALU"] / sq["SQ_WAVES"] / ipl,
+           "fp64_source": f"profiles/{tag}/pmc_sq.csv: (2 FMA + ADD + MUL + TRANS)_F64 x 64 lanes x SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU), "
+                          "mean of the last third of the dispatches",
+           "bench_value_when_profiled": bench["value"], "bench_ms_per_step_when_profiled": bench["ms_per_step"],
+           "rocprof_avg_launch_ms": float(next(r for r in stats if r["Name"].split("(")[0] == dom)["AverageNs"]) / 1e6,
+           # all launches of the run, per draw: setup draws + --warmup + the timed regions (bench.py: SETUP_DRAWS = 150, REPEATS = 5)
+           "rocprof_ms_per_iteration_all_kernels": sum(float(r["TotalDurationNs"]) for r in stats) / 1e6 / (150 + bench["warmup"] + 5 * bench["steps"] + (0 if ipl > 1 else min(bench["steps"], 20)))}
 json.dump(tj, open(tj_path, "w"), indent=1)
 print(open(f"{out}/kernel_stats.csv").read()[:1500])
 print(json.dumps(tj[key], indent=1))

@@ -1,5 +1,5 @@
 """Cycle split of the octet kernel's iteration (diagnostic build -DKLHR_STAMPS, loaded through KLHR_LIB).
-Check the diagnostic build against the production library first (tools/dbg_libcmp_iter.py with and without KLHR_LIB):
+Check the diagnostic build against the production library first (tools/libcmp_iter.py with and without KLHR_LIB):
 an earlier octet build with stamps was miscompiled (open issues)."""
 import os, sys
 ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,ROOT)
