@@ -792,3 +792,40 @@ def test_fit_kernel_forms_agree_over_a_population(monkeypatch, kernel_mode, name
     for o in out[1:]:
         for a, b in zip(out[0], o):
             assert np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.parametrize("name", ["glmm45", "funnel10", "funnel100", "illnormal100", "ar1x100", "earnings", "normal2"])
+@pytest.mark.parametrize("variant,over,flags", [(0, False, {}), (0, True, {}), (1, False, {}), (1, True, {}), (2, False, {}), (2, True, {}),
+                                                (0, False, {"eigen_method_one": True})])
+def test_free_running_octets_equal_lockstep_octets(monkeypatch, kernel_mode, name, variant, over, flags):
+    """The general hot path (klhr_free_kernel: octets advance through their own iterations, O(D) phases served by the whole
+    wavefront) against the lock-step octet kernel (klhr_iter_kernel).  With KLHR_FREE_MH=exact the MH step's two log densities
+    come from the same index-order loop, and then every bit of every chain's state and of the recorded draws is the same —
+    across both window closures (warmup = 100), several launches (KLHR_CHUNK), a partly empty last wavefront and recorded
+    diagnostics.  Without it (the production form: octet-cooperative line evaluation of the two values) log r moves at
+    rounding level: the accept decisions and the draws stay the same on these runs to 1e-9."""
+    if kernel_mode != "auto":
+        pytest.skip("this test selects the two octet kernels itself")
+    stem, data = model_spec(name)
+    C = 21
+    seeds = np.arange(C, dtype=np.uint64) + 8800
+    tol, sc = (1e-12, 600) if variant == 1 else (1e-10, 300)
+    fields = ("theta", "rng", "mean", "cov", "eigvecs", "eigvals", "om_m", "om_v", "pca_v", "grad_evals", "acc", "counters", "status", "kstate")
+    out = {}
+    monkeypatch.setenv("KLHR_CHUNK", "37")
+    for mode, mh in (("octet", ""), ("free", "exact"), ("free", "")):
+        monkeypatch.setenv("KLHR_KERNEL", mode)
+        monkeypatch.setenv("KLHR_FREE_MH", mh)
+        s = make_sampler(stem, data, C, warmup=100, variant=variant, overrelaxed=over, tol=tol, scale_clip=sc, **flags)
+        assert ("free" in s.kernel_name()) == (mode == "free"), s.kernel_name()
+        s.seed(seeds)
+        s.step(120, record_draws=True)
+        d = s.draws(0, 120)
+        s.step(7, record_diag=True)
+        out[(mode, mh)] = [d] + [s.get(f) for f in fields] + [s.get("diag"), s.get("rho"), s.get("eta")]
+    for a, b in zip(out[("octet", "")], out[("free", "exact")]):
+        assert np.array_equal(a, b, equal_nan=True)
+    a, b = out[("octet", "")], out[("free", "")]
+    ok = np.isfinite(a[0]).all(axis=(0, 2))
+    assert np.allclose(a[0][:, ok], b[0][:, ok], rtol=1e-9, atol=1e-9)
+    assert np.array_equal(a[2][ok], b[2][ok])          # the generator's position: same draws consumed, same decisions

@@ -75,7 +75,7 @@ tj[key] = {"kernel": dom, "build_id": bench["build_id"], "profile_dir": f"profil
            "hbm_bytes_per_launch": fetch + write, "fetch_bytes_calibrated": fetch, "fetch_bytes_raw": fetch_raw, "write_bytes": write,
            "iters_per_launch": ipl, "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_chain_iter"] * bench["config"]["chains_per_gpu"] * ipl,
            "source": f"profiles/{tag}/pmc_fetch_write.csv (mean of the last third of the dispatches); FETCH_SIZE / {FETCH_FACTOR}: calibration of the "
-                     f"{'tiled 8-byte coalesced' if cal == 'tiled' else 'lane-private row'} read pattern, profiles/r0{1b,2_calibration,3_calibration}/rowcal.csv",
+                     f"{'tiled 8-byte coalesced' if cal == 'tiled' else 'lane-private row'} read pattern, profiles/r01b, r02_calibration, r03_calibration (rowcal.csv)",
            "fp64_flops_per_launch": fp64_insts * 64 * lanes_active, "lanes_active": lanes_active,
            "valu_active": sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"], "waiting": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"],
            "valu_per_wavefront_iter": sq["SQ_INSTS_VALU"] / sq["SQ_WAVES"] / ipl,
