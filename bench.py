@@ -236,13 +236,16 @@ def run_workload(model, dim, C, steps, warm, repeats, rank, world, device, seed,
 
 
 def ess_run(device, seed, value):
-    """ESS of the funnel-10D chains from a fixed run outside every timed region: 512 chains, the same setup draws, 3 000
-    burn-in draws (the chains start at 0.1 z and need ~3 000 draws to spread over v ~ N(0, 3)), then 20 000 recorded draws.
-    ESS/sec = ESS per chain-iteration x the headline iterations/sec (all chains).  An estimate whose Geyer truncation lag
-    is not below a tenth of the run is bounded by the window rather than by the chain: reported as null with the reason."""
+    """ESS of the funnel-10D chains from a fixed run outside every timed region.  The funnel's v mixes slowly under hit-and-run
+    (measured: integrated autocorrelation time ~5 000 draws), so the run is long and narrow: 128 chains, the same setup draws,
+    20 000 burn-in draws, then 250 000 recorded draws (~45 s: a launch of two wavefronts is as long as its chain of dependent
+    iterations, ~0.17 ms each, however few chains it holds).  ESS/sec = ESS per chain-iteration x the headline iterations/sec
+    (all chains).  An estimate whose Geyer truncation lag is not below a tenth of the run is bounded by the window rather than
+    by the chain: reported as null with the reason; `tau.between_chains` (run length x variance of the chain means / pooled
+    variance) is the cross-check that needs no truncation."""
     from klhr_amd import _lib
     from klhr_amd.ess import ess_detail
-    nch, burn, ndraw = 512, 3000, 20000
+    nch, burn, ndraw = 128, 20000, 250000
     data, D = model_data("funnel", 10)
     s = _lib.Sampler(_lib.MODEL_IDS["funnel"], data, nch, device=device, warmup=100)
     s.seed(np.uint64(seed) + np.uint64(7_000_000) + np.arange(nch, dtype=np.uint64))
@@ -255,6 +258,8 @@ def ess_run(device, seed, value):
     dr = s.draws(0, ndraw)
     s.close()
     det = [ess_detail(dr[:, :, j]) for j in range(D)]
+    v = dr[:, :, 0]
+    tau_between = float(ndraw * v.mean(axis=0).var(ddof=1) / v.var())
 
     def per_iter(d):
         return d["ess"] / (nch * ndraw)
@@ -265,7 +270,7 @@ def ess_run(device, seed, value):
            "ess_per_chain_iteration": {"v": per_iter(det[0]), "min_coord": per_iter(det[jmin]), "v_on_half_the_run": half[0],
                                        "min_coord_on_half_the_run": half[1]},
            "tau": {"v": det[0]["tau"], "min_coord": det[jmin]["tau"], "max_truncation_lag": max(d["truncation_lag"] for d in det),
-                   "draws_per_chain": ndraw},
+                   "draws_per_chain": ndraw, "v_between_chains": tau_between},
            "rhat": {"v": det[0]["rhat"], "max": max(d["rhat"] for d in det)},
            "moments_of_v": {"mean": float(dr[:, :, 0].mean()), "sd": float(dr[:, :, 0].std()), "target": "N(0, 3)"},
            "estimated_on": {"chains": nch, "burn_in_draws": SETUP_DRAWS + burn, "draws": ndraw, "its_own_it_per_s": nch * ndraw / dt},
@@ -385,9 +390,18 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             ncpu = os.cpu_count() or 1
             try:
-                ncpu = len(os.sched_getaffinity(0))          # the cores this process may actually use (a 1-GPU box hands out a share)
+                ncpu = len(os.sched_getaffinity(0))          # the cores this process may actually use ...
             except (AttributeError, OSError):
                 pass
+            quota = None
+            try:                                             # ... and the CPU time its cgroup grants (a 1-GPU box hands out a share of the host)
+                q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+                if q != "max":
+                    quota = max(1, int(float(q) / float(per)))
+            except (OSError, ValueError):
+                pass
+            if quota:
+                ncpu = min(ncpu, quota)
             threads = min(ncpu, 16)
             n_cpu_chains, cpu_iters = 256 * threads, 200        # ~1.2 s wall on 16 threads = ~19 s of CPU work
             v = cpu_baseline(n_cpu_chains, 100, cpu_iters, threads)
@@ -400,7 +414,8 @@ def main():
             out["cpu_baseline"] = {"value": v, "unit": "iterations/s", "cores": threads, "kind": "port",
                                    "sample": f"CPU oracle (C restatement of the reference path, OpenMP over chains): {n_cpu_chains} funnel-10D chains x {cpu_iters} draws after 100 warmup draws",
                                    "single_thread": {"value": v1, "unit": "iterations/s", "sample": "64 funnel-10D chains x 200 draws after 100 warmup draws, 1 thread"},
-                                   "all_cores": allc, "host_cpus_usable": ncpu,
+                                   "all_cores": allc, "host_cpus_usable": ncpu, "cgroup_cpu_quota": quota,
+                                   "all_cores_note": None if allc else f"this process may use {ncpu} CPUs (affinity mask and cgroup quota): the {threads}-thread figure is the all-core total",
                                    "cpu_model": cpu_model_string(), "host_cpus": os.cpu_count(),
                                    "reference_python": {"it_per_s_per_chain": [59.4, 78.4], "unit": "iterations/s per chain",
                                                         "where": "BASELINE.md section 2: the reference's own klhr_sinh.py, NumPy stand-in model, 1 core of the build container (the reference cannot travel to the GPU box)"}}

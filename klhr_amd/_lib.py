@@ -226,7 +226,7 @@ class Sampler:
         stream = "klhr_stream16_kernel" if self._L.klhr_tile_width(self._h) == 16 else "klhr_stream_kernel"
         return {0: ["klhr_iter_kernel"], 1: ["klhr_lane_kernel"], 2: [stream, "(none)", "klhr_fit12_kernel"],
                 3: [stream, "(none)", "klhr_fitn_kernel"],
-                5: ["klhr_tile_kernel"], 6: ["klhr_free_kernel"]}[self._L.klhr_kernel_variant(self._h)]
+                5: ["klhr_tile_kernel"]}[self._L.klhr_kernel_variant(self._h)]
 
     def kernel_name(self):
         return "+".join(n for n in self.kernel_names() if n != "(none)")

@@ -1,9 +1,8 @@
 """Build libklhr_hip.so for gfx950 in-tree (klhr_amd/lib/).  `python -m klhr_amd.build [--force] [-v]`
 
-Seventeen translation units are compiled in parallel and linked: klhr_api.hip (C ABI + small kernels), klhr_hot.hip once per
-(sampler variant, over-relaxation) pair (six) plus once for the slice sampler — see the comment at the top of klhr_hot.hip —,
-klhr_split.hip once per variant (three) and klhr_free.hip once per (variant, over-relaxation) pair (six).  Only the units
-whose sources or flags changed are recompiled.
+Eleven translation units are compiled in parallel and linked: klhr_api.hip (C ABI + small kernels), klhr_hot.hip once per
+(sampler variant, over-relaxation) pair (six) plus once for the slice sampler — see the comment at the top of klhr_hot.hip —
+and klhr_split.hip once per variant (three).  Only the units whose sources or flags changed are recompiled.
 
 Every unit's device assembly is kept (-save-temps) and checked with tools/exec_lint.py: at 256 VGPR + ~250 AGPR the
 register allocator has been seen to place AGPR save copies ahead of a block's EXEC restore (they then save nothing and
@@ -20,8 +19,7 @@ SRC = os.path.join(HERE, "csrc")
 OUT = os.environ.get("KLHR_BUILD_OUT") or os.path.join(HERE, "lib", "libklhr_hip.so")      # KLHR_BUILD_OUT: diagnostic builds
 OBJ = os.path.join(os.path.dirname(OUT), "obj" if not os.environ.get("KLHR_BUILD_OUT") else "obj_diag")
 COMMON = ["klhr_kernels.hpp", "device_opt.hpp", "device_models.hpp", "device_rng.hpp", "zig_tables.h", os.path.join("..", "..", "include", "klhr.h")]
-UNIT_DEPS = {"api": ["klhr_api.hip"], "hot": ["klhr_hot.hip", "klhr_lane_kernel.hpp"], "split": ["klhr_split.hip", "klhr_split.hpp", "klhr_lane_kernel.hpp"],
-             "free": ["klhr_free.hip", "klhr_free_kernel.hpp"]}
+UNIT_DEPS = {"api": ["klhr_api.hip"], "hot": ["klhr_hot.hip", "klhr_lane_kernel.hpp"], "split": ["klhr_split.hip", "klhr_split.hpp", "klhr_lane_kernel.hpp"]}
 DEPS = sorted(set(COMMON + [d for v in UNIT_DEPS.values() for d in v]))
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"]
 # diagnostic builds: KLHR_EXTRA_FLAGS (e.g. -DKLHR_STAMPS) for the units whose name starts with one of KLHR_EXTRA_UNITS (comma
@@ -101,9 +99,6 @@ def build(force=False, verbose=False, extra=()):
     jobs.append(("hot_v3_o0.o", "hot", ["-c", os.path.join(SRC, "klhr_hot.hip"), "-DKLHR_VARIANT=3", "-DKLHR_OVERRELAX=0"]))     # slice.py
     for v in (0, 1, 2):           # split-phase pipeline (klhr_split.hpp), one unit per variant
         jobs.append((f"split_v{v}.o", "split", ["-c", os.path.join(SRC, "klhr_split.hip"), f"-DKLHR_VARIANT={v}"]))
-    for v in (0, 1, 2):           # free-running octet kernel (klhr_free_kernel.hpp)
-        for o in (0, 1):
-            jobs.append((f"free_v{v}_o{o}.o", "free", ["-c", os.path.join(SRC, "klhr_free.hip"), f"-DKLHR_VARIANT={v}", f"-DKLHR_OVERRELAX={o}"]))
 
     def objpath(name):
         return os.path.join(OBJ, name[:-2], name)

@@ -23,13 +23,6 @@ void launch_hot_v1_o1(const KParams &, int, bool, hipStream_t);
 void launch_hot_v2_o0(const KParams &, int, bool, hipStream_t);
 void launch_hot_v2_o1(const KParams &, int, bool, hipStream_t);
 void launch_hot_v3_o0(const KParams &, int, bool, hipStream_t);
-// free-running octet kernel (klhr_free.hip), one unit per (variant, over-relaxation) pair
-void launch_free_v0_o0(const KParams &, int, int, hipStream_t);
-void launch_free_v0_o1(const KParams &, int, int, hipStream_t);
-void launch_free_v1_o0(const KParams &, int, int, hipStream_t);
-void launch_free_v1_o1(const KParams &, int, int, hipStream_t);
-void launch_free_v2_o0(const KParams &, int, int, hipStream_t);
-void launch_free_v2_o1(const KParams &, int, int, hipStream_t);
 // split-phase pipeline (klhr_split.hip), one unit per variant: what = 0 stream, 3 probe, 4 / 8 fit, 7 whole iterations per tile
 void launch_split_v0(const KParams &, int, int, bool, int, int, hipStream_t);
 void launch_split_v1(const KParams &, int, int, bool, int, int, hipStream_t);
@@ -97,9 +90,6 @@ struct klhr_sampler {
     int C = 0, D = 0, ncol = 0, S = 0, S_lane = 0, n_model = 0;
     bool use_lane = false;       // lane-per-chain kernel (small D) instead of the octet-per-chain kernel
     bool split = false;          // split-phase pipeline (klhr_split.hpp): tiled state layout, two kernels per iteration
-    bool use_free = false;       // octet mapping: whole draws (klhr_step) run on the free-running octet kernel (klhr_free_kernel.hpp)
-    int mh_exact = 0;            // ... with the MH step's log densities by the index-order loop (KLHR_FREE_MH=exact: bit-compare with klhr_iter_kernel)
-    bool last_free = false;      // the most recent klhr_step ran on klhr_free_kernel
     size_t Cp = 0;               // chains the [C][D...] arrays are allocated for (whole tiles in the tiled layout)
     int tw = 64;                 // tile width of the tiled layout: chains per tile = lanes of a streaming wavefront in use
     int groups = 1;              // klhr_step runs the chains as this many groups on separate HIP streams (split pipeline)
@@ -227,7 +217,7 @@ extern "C" const char *klhr_last_error(const klhr_sampler *s) { return s ? s->er
 extern "C" int klhr_dim(const klhr_sampler *s) { return s ? s->D : KLHR_ERR_ARG; }
 extern "C" int klhr_chains(const klhr_sampler *s) { return s ? s->C : KLHR_ERR_ARG; }
 extern "C" int klhr_tile_width(const klhr_sampler *s) { return s ? (s->split ? s->tw : 0) : KLHR_ERR_ARG; }
-extern "C" int klhr_kernel_variant(const klhr_sampler *s) { return s ? (s->split ? (s->fused ? 5 : (s->fitn ? 3 : 2)) : (s->use_lane ? 1 : (s->use_free ? 6 : 0))) : KLHR_ERR_ARG; }
+extern "C" int klhr_kernel_variant(const klhr_sampler *s) { return s ? (s->split ? (s->fused ? 5 : (s->fitn ? 3 : 2)) : (s->use_lane ? 1 : 0)) : KLHR_ERR_ARG; }
 
 // ---- host <-> device copies of [C][W] state arrays: the host side is always chain-major (the NumPy layout); the device
 // side is tiled [tile][w][64 lanes] for handles of the split pipeline
@@ -364,17 +354,12 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
     if (cfg->variant == 3) s->use_lane = false;          // the slice sampler runs on the octet kernel only
     else
     if (const char *kk = getenv("KLHR_KERNEL")) {
-        if (!strcmp(kk, "octet") || !strcmp(kk, "free")) { s->use_lane = false; s->split = false; }
+        if (!strcmp(kk, "octet")) { s->use_lane = false; s->split = false; }
         else if (!strcmp(kk, "lane")) { s->split = false; if (((size_t)64 * SL + 1072) * 8 <= 64 * 1024) s->use_lane = true; }
         else if (!strcmp(kk, "mono")) s->split = false;
         else if (!strcmp(kk, "split")) s->split = split_ok;
     }
     if (s->split) s->use_lane = false;
-    // octet mapping: whole draws run with free-running octets (klhr_free_kernel.hpp) — every variant but the slice sampler, without
-    // scale_dir_cov (its gradient pass belongs to the lock-step kernel); KLHR_KERNEL=octet keeps the lock-step kernel for everything
-    s->use_free = !s->split && !s->use_lane && cfg->variant != 3 && !cfg->scale_dir_cov;
-    if (const char *kk = getenv("KLHR_KERNEL")) if (!strcmp(kk, "octet")) s->use_free = false;
-    if (const char *e = getenv("KLHR_FREE_MH")) s->mh_exact = !strcmp(e, "exact") ? 1 : 0;
     if (s->split) {
         // Tile width of the streaming kernel: 64 lanes per tile use the whole wavefront; with few chains a launch lasts as long
         // as one wavefront's walk through its phases whatever the width, and 16-chain tiles can run a tile's tail and head
@@ -514,16 +499,6 @@ static int launch_iter(klhr_sampler *s, const KParams &kp_in) {
     KParams kp = kp_in;
     kp.S = s->use_lane ? s->S_lane : s->S;
     const bool o = s->cfg.overrelaxed != 0;
-    s->last_free = false;
-    if (s->use_free && kp.phases == PH_ALL) {
-        // whole draws on the octet mapping: free-running octets (the pieces of the C ABI and the probes use klhr_iter_kernel)
-        s->last_free = true;
-        if (s->cfg.variant == 2) (o ? launch_free_v2_o1 : launch_free_v2_o0)(kp, s->cfg.model_id, s->mh_exact, s->stream);
-        else if (s->cfg.variant == 1) (o ? launch_free_v1_o1 : launch_free_v1_o0)(kp, s->cfg.model_id, s->mh_exact, s->stream);
-        else (o ? launch_free_v0_o1 : launch_free_v0_o0)(kp, s->cfg.model_id, s->mh_exact, s->stream);
-        HIPCHECK(s, hipGetLastError());
-        return 0;
-    }
     if (s->cfg.variant == 3) launch_hot_v3_o0(kp, s->cfg.model_id, false, s->stream);
     else if (s->cfg.variant == 2) (o ? launch_hot_v2_o1 : launch_hot_v2_o0)(kp, s->cfg.model_id, s->use_lane, s->stream);
     else if (s->cfg.variant == 1) (o ? launch_hot_v1_o1 : launch_hot_v1_o0)(kp, s->cfg.model_id, s->use_lane, s->stream);

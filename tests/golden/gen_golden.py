@@ -224,6 +224,42 @@ def g4_kl():
     np.savez(os.path.join(HERE, "g4_kl.npz"), **out)
 
 
+def g4c_kl_clip():
+    """G4c: KL(eta, rho) of the reference with scale_clip = 3 — the element-wise gradient clip of _logp_grad
+    (klhr_sinh.py:158-161) is then ACTIVE at most quadrature nodes, on every target (G4 holds 70 clip-active nodes on the
+    funnel / ill-normal and none on ar1): the closed-form kernels must take their exact element-wise patch there.
+    `*_nclip` = number of (node, coordinate) pairs whose gradient component is clipped, per point."""
+    out = {}
+    for name in ["funnel10", "funnel100", "illnormal100", "ar1x100", "normal2", "glmm45", "earnings"]:
+        model = make_model(name)
+        a = ref_klhr_sinh.KLHRSINH(model, seed=11, overrelaxed=False, scale_clip=3.0)
+        D = a.D
+        g = np.random.default_rng(43)
+        n = 64
+        thetas = g.normal(size=(n, D)) * np.where(np.arange(n) % 4 == 3, 2.5, 1.0)[:, None]
+        rhos = g.normal(size=(n, D))
+        rhos /= np.linalg.norm(rhos, axis=1)[:, None]
+        etas = g.normal(size=(n, 4)) * 0.3
+        etas[n // 2:, 1] += 0.8
+        if name == "earnings":
+            thetas[::2] = np.array([-6e4, 1.25e3, 9.85, 7.0]) + g.normal(size=(n // 2, 4)) * np.array([3e3, 40.0, 0.05, 0.5])
+        vals = np.zeros(n)
+        grads = np.zeros((n, 4))
+        nclip = np.zeros(n, dtype=np.int64)
+        with np.errstate(all="ignore"):
+            for i in range(n):
+                a.theta = thetas[i]
+                vals[i], grads[i] = a.KL(etas[i], rhos[i])
+                for xn in a.x:
+                    z = a._T(xn, etas[i])
+                    _, gr = model.log_density_gradient(thetas[i] + z * rhos[i])
+                    nclip[i] += int(np.sum(np.abs(gr) > 3.0))
+        out.update({f"{name}_theta": thetas, f"{name}_rho": rhos, f"{name}_eta": etas, f"{name}_kl": vals, f"{name}_klgrad": grads,
+                    f"{name}_nclip": nclip})
+    out["scale_clip"] = np.array([3.0])
+    np.savez(os.path.join(HERE, "g4c_kl_clip.npz"), **out)
+
+
 def g7_online():
     out = {}
     g = np.random.default_rng(71)
@@ -617,8 +653,8 @@ def g10_overrelaxed():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g7", "g8", "g8p", "g9", "g10", "g11", "g12", "g13"]
-    fns = {"g1": g1_quadrature, "g2": g2_rng, "g3": g3_primitives, "g4": g4_kl, "g7": g7_online,
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g4c", "g7", "g8", "g8p", "g9", "g10", "g11", "g12", "g13"]
+    fns = {"g1": g1_quadrature, "g2": g2_rng, "g3": g3_primitives, "g4": g4_kl, "g4c": g4c_kl_clip, "g7": g7_online,
            "g8": g8_chains, "g8p": g8_untouched, "g9": g9_mh, "g10": g10_overrelaxed, "g11": g11_klhr, "g12": g12_sub, "g13": g13_slice}
     for w in which:
         print("==", w, flush=True)

@@ -68,3 +68,27 @@ def make_sampler(stem, data, chains, **kw):
     from klhr_amd import _lib
     from oracle.oracle import model_data
     return _lib.Sampler(_lib.MODEL_IDS[stem], model_data(stem, data), chains, **kw)
+
+
+STATE_FIELDS = ["theta", "rng", "mean", "cov", "eigvecs", "eigvals", "om_m", "om_v", "pca_v"]
+
+
+def oracle_state_trace(oracle, stem, data, seed, n, **kw):
+    """Run one oracle chain for n draws; per draw the chain's full state BEFORE it (every field a device chain needs to take the same
+    draw: theta, generator, adaptation state, counters) and theta / generator / acceptance count AFTER it.  Lets a test hand
+    every draw of a trajectory to its own device chain (teacher forcing with the oracle's own states, any constructor arguments)."""
+    c = oracle.Chain(stem, data, seed=seed, **kw)
+    before = {f: [] for f in STATE_FIELDS}
+    cnt, acc_b, theta_a, rng_a, acc_a, eta_a, diag_a = [], [], [], [], [], [], []
+    for m in range(n):
+        for f in STATE_FIELDS:
+            before[f].append(np.array(c.get(f), copy=True))
+        cnt.append([c.get("draw"), c.get("om_N"), c.get("pca_n"), c.get("cidx")])
+        acc_b.append(c.get("acc"))
+        c.draw()
+        theta_a.append(c.get("theta").copy()); rng_a.append(c.get("rng").copy()); acc_a.append(c.get("acc"))
+        eta_a.append(c.get("eta").copy()); diag_a.append(c.get("diag"))
+    out = {f: np.array(v) for f, v in before.items()}
+    out.update(counters=np.array(cnt, dtype=np.int64), acc_before=np.array(acc_b), theta_after=np.array(theta_a), rng_after=np.array(rng_a),
+               acc_after=np.array(acc_a), eta_after=np.array(eta_a), diag_after=diag_a)
+    return out

@@ -101,3 +101,36 @@ def test_mapping_thresholds_do_not_show_in_a_chain(name):
         else:
             for a, b in zip(ref, st):
                 assert np.array_equal(a, b), (C, s.kernel_name())
+
+
+def test_cfg5_pooled_shard_full_size_through_rccl(kernel_mode):
+    """BASELINE config 5's per-GPU shard at full size in POOLED mode: funnel-100D, 131 072 chains, pooled="full" with the collective
+    inside the library (klhr_comm_init with a one-rank communicator: ncclAllReduce of 1 + D + D^2 doubles on the handle's
+    stream) through BOTH window closures of warmup = 100 — the LDS-tiled MFMA Gram kernel over 49 x 131 072 and 99 x 131 072
+    draws.  Every chain carries the same pooled mean / diagonal / eigenvectors afterwards, and the pooled mean is the window's
+    column sum over its row count as the all-reduced statistics hold them."""
+    if kernel_mode != "auto":
+        pytest.skip("the production mapping of this configuration (split pipeline, 64-chain tiles)")
+    from klhr_amd import BSModel
+    from klhr_amd.parallel import ShardedKLHRSINH
+    import os
+    from conftest import STAN
+    m = BSModel(os.path.join(STAN, "funnel.stan"), data={"D": 99})
+    assert m.dim() == 100
+    C = 131072
+    sh = ShardedKLHRSINH(m, C, seed=77, pooled="full", rccl=True, warmup=100)
+    s = sh.local._sampler
+    assert s.comm_world() == 1 and "stream" in s.kernel_name()
+    sh.advance(49)
+    s.pool_allreduce()
+    tot = s.pool_fetch()
+    assert tot[0] == 49 * C
+    sh.advance(1)                      # first closure: pooled values installed
+    mean, cov, evec = s.get("mean"), s.get("cov"), s.get("eigvecs")
+    assert np.all(mean == mean[0]) and np.all(cov == cov[0]) and np.all(evec == evec[0])
+    assert np.allclose(mean[0], tot[1:101] / tot[0], rtol=1e-12, atol=1e-14)
+    sh.advance(60)                     # second closure (draw 100) and ten draws beyond it
+    mean2, cov2 = s.get("mean"), s.get("cov")
+    assert np.all(mean2 == mean2[0]) and np.all(cov2 == cov2[0]) and not np.array_equal(mean2[0], mean[0])
+    assert np.isfinite(s.get("theta")).all() and not s.get("status").any()
+    assert np.all(s.get("counters")[:, 0] == 110)

@@ -42,7 +42,7 @@ def test_instantiation_matches_oracle(oracle, monkeypatch, kernel_mode, name, la
     ok = np.isfinite(ref).all(axis=(0, 2))
     assert ok.sum() >= NCHAINS - 2, "oracle chains went non-finite"
     kernels = ["lane", "octet"] if (lane_ok and variant != 3) else ["octet"]
-    if stem in ("funnel", "ill-normal", "normal") and variant != 3:
+    if stem in ("funnel", "ill-normal", "normal", "ar1") and variant != 3:
         kernels.append("split")                                                 # split-phase pipeline (klhr_split.hpp)
     for kernel in kernels:
         monkeypatch.setenv("KLHR_KERNEL", kernel)

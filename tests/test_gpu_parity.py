@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN, golden, model_spec
-from parity_util import make_sampler, oracle_teacher_forced, parse_g8
+from parity_util import STATE_FIELDS, oracle_state_trace, make_sampler, oracle_teacher_forced, parse_g8
 
 pytestmark = pytest.mark.gpu
 
@@ -85,6 +85,37 @@ def test_models_kl_line_vs_golden_and_oracle(oracle, name):
             assert abs(v[i] - vo) <= 1e-12 * max(1.0, abs(vo))
 
 
+@pytest.mark.parametrize("name", MODELS)
+def test_kl_with_the_gradient_clip_active_vs_reference(oracle, name):
+    """G4c (the reference's KL with scale_clip = 3: the clip bites at nearly every node, ar1 included).  On the closed-form
+    kernels every such node fails line_point's clip bound and is recomputed by the exact element-wise patch (lane kernel:
+    model_eval_nv<MODEL, 1> over the LDS row; split pipeline: exact_points4 from the tiled rows) — checked here against the
+    reference's numbers, in every kernel mode, and against the oracle."""
+    g = golden("g4c_kl_clip.npz")
+    if f"{name}_theta" not in g.files:
+        pytest.skip("no G4c points for this target")
+    stem, data = model_spec(name)
+    th, rho, eta = g[f"{name}_theta"], g[f"{name}_rho"], g[f"{name}_eta"]
+    n = th.shape[0]
+    sc = float(g["scale_clip"][0])
+    s = make_sampler(stem, data, n, warmup=100, scale_clip=sc)
+    s.set("theta", th)
+    v, gr = s.kl_eval(eta, rho)
+    ref_v, ref_g = g[f"{name}_kl"], g[f"{name}_klgrad"]
+    ok = np.isfinite(ref_v) & np.all(np.isfinite(ref_g), axis=1)
+    assert ok.sum() >= n - 2 and (g[f"{name}_nclip"][ok] > 0).sum() >= 58
+    scale = np.maximum(1.0, np.abs(ref_v[ok]))
+    assert np.all(np.abs(v[ok] - ref_v[ok]) <= 1e-12 * scale), np.max(np.abs(v[ok] - ref_v[ok]) / scale)
+    gs = np.maximum(1.0, np.abs(ref_g[ok]).max(axis=1))[:, None]
+    assert np.all(np.abs(gr[ok] - ref_g[ok]) <= 1e-11 * gs), np.max(np.abs(gr[ok] - ref_g[ok]) / gs)
+    for i in range(0, n, 5):
+        o = oracle.Chain(stem, data, seed=1, scale_clip=sc)
+        o.set("theta", th[i])
+        vo, go = o.KL(eta[i], rho[i])
+        if np.isfinite(vo):
+            assert abs(v[i] - vo) <= 1e-12 * max(1.0, abs(vo))
+
+
 def test_primitives_vs_golden():
     g = golden("g3_primitives.npz")
     stem, data = model_spec("normal2")
@@ -144,7 +175,8 @@ def ill_conditioned(oracle, R, m, init):
 def test_teacher_forced_pieces_vs_oracle(oracle, fn):
     """Every record of a golden chain trace becomes one GPU chain: same state before the draw, then each piece of
     draw() is run on the device and compared with the oracle's result for that record (and with the reference's)."""
-    R = oracle_teacher_forced(oracle, fn, max_records=400)
+    # (the four cfg1 fixtures — funnel-10, seeds 0-3, 1 000 draws each — are teacher-forced over all their records, the others over 400)
+    R = oracle_teacher_forced(oracle, fn, max_records=None if fn.startswith("g8_funnel10_s") and fn[13] in "0123" and fn.endswith("_w100.npz") else 400)
     g, M, flags = R["g"], R["M"], R["flags"]
     s = make_sampler(R["stem"], R["data"], M, warmup=R["warmup"], **flags)
     s.set("theta", g["theta_before"][:M])
@@ -206,6 +238,8 @@ def test_teacher_forced_pieces_vs_oracle(oracle, fn):
         print(f"{fn}: record {m}: eta differs by {worst_o[np.flatnonzero(sel) == m][0]:.2e} at equal evaluation counts; "
               f"the oracle's own minimiser moves by {moved:.2e} under a one-ulp change of one component of init")
         assert moved > 1e-7, (fn, m, moved)
+        # the allowance is tied to the measured sensitivity: the device may be off by at most 100 x what a one-ulp nudge does to the oracle
+        assert worst_o[np.flatnonzero(sel) == m][0] <= 100.0 * moved, (fn, m, worst_o[np.flatnonzero(sel) == m][0], moved)
         # ... and both fits reached the same objective value to the level gtol = 1e-3 implies
         assert abs(d[m, col["fun2"]] - o_rec["fun2"]) <= 1e-5 * (1.0 + abs(o_rec["fun2"])), (fn, m)
     assert np.all(d[sel, col["status1"]] == 0) and np.all(d[sel, col["status2"]] == 0)
@@ -243,8 +277,9 @@ def test_teacher_forced_pieces_vs_oracle(oracle, fn):
         if not same[m]:
             continue          # stopped an evaluation apart from the oracle: a decision-boundary record, bounded through its KL value above
         near_oracle = err[m].max() <= tol_eta and gap[m] >= 0.5 * errr[m].max()
-        assert near_oracle or ill_conditioned(oracle, R, m, [o_rec["init0"], o_rec["init1"], o_rec["init2"], o_rec["init3"]]) > 1e-7, \
-            (fn, m, errr[m].max(), gap[m], err[m].max())
+        if not near_oracle:
+            moved = ill_conditioned(oracle, R, m, [o_rec["init0"], o_rec["init1"], o_rec["init2"], o_rec["init3"]])
+            assert moved > 1e-7 and err[m].max() <= 100.0 * moved, (fn, m, errr[m].max(), gap[m], err[m].max(), moved)
     # ---- a12 MH step from the reference's eta and rho
     s.set("counters", R["cnt_before"])
     s.set("acc", R["acc_before"])
@@ -794,38 +829,59 @@ def test_fit_kernel_forms_agree_over_a_population(monkeypatch, kernel_mode, name
             assert np.array_equal(a, b, equal_nan=True)
 
 
-@pytest.mark.parametrize("name", ["glmm45", "funnel10", "funnel100", "illnormal100", "ar1x100", "earnings", "normal2"])
-@pytest.mark.parametrize("variant,over,flags", [(0, False, {}), (0, True, {}), (1, False, {}), (1, True, {}), (2, False, {}), (2, True, {}),
-                                                (0, False, {"eigen_method_one": True})])
-def test_free_running_octets_equal_lockstep_octets(monkeypatch, kernel_mode, name, variant, over, flags):
-    """The general hot path (klhr_free_kernel: octets advance through their own iterations, O(D) phases served by the whole
-    wavefront) against the lock-step octet kernel (klhr_iter_kernel).  With KLHR_FREE_MH=exact the MH step's two log densities
-    come from the same index-order loop, and then every bit of every chain's state and of the recorded draws is the same —
-    across both window closures (warmup = 100), several launches (KLHR_CHUNK), a partly empty last wavefront and recorded
-    diagnostics.  Without it (the production form: octet-cooperative line evaluation of the two values) log r moves at
-    rounding level: the accept decisions and the draws stay the same on these runs to 1e-9."""
+SPLIT_FORMS = {"fit12": {"KLHR_KERNEL": "split", "KLHR_FITN": "0", "KLHR_FUSED": "0"}, "fitn": {"KLHR_KERNEL": "split", "KLHR_FITN": "1", "KLHR_FUSED": "0"},
+               "tile": {"KLHR_KERNEL": "split", "KLHR_FITN": "1", "KLHR_FUSED": "1"}, "mono": {"KLHR_KERNEL": "mono"}}
+
+
+@pytest.mark.parametrize("name", ["funnel10", "funnel100", "illnormal100", "ar1x100"])
+@pytest.mark.parametrize("form", ["fit12", "fitn", "tile", "mono"])
+def test_exact_patch_draws_vs_oracle(oracle, monkeypatch, kernel_mode, name, form):
+    """The closed-form kernels' exact element-wise patch INSIDE THE FIT, against the oracle.  With scale_clip = grad_clip = 3 the
+    clip of _logp_grad (klhr_sinh.py:158-161) bites at most quadrature nodes, so line_point's bound fails and nearly every KL
+    evaluation of a fit takes the patch (at the defaults: 1 in 2 000-6 000).  (a) Free-running: 24 chains x 49 draws against
+    oracle.Chain(scale_clip=3, grad_clip=3) — funnel / ill-normal follow the oracle to 1e-9 over all 49 draws (a chain may leave
+    at a knife-edge decision: at most 2 of 24, and the element-wise octet kernel loses the same ones); on ar1 the KL of a
+    Gaussian target is flat in the tail parameters and free-running chains part from ANY other arithmetic within ~5 draws
+    (the octet kernel, which has no closed form, does too), so there (b) carries the weight.  (b) Teacher-forced: every draw of two
+    oracle trajectories (2 x 60 records, both window closures) is handed to its own device chain with the oracle's state before
+    it; one whole draw through the production kernels; generator position identical, theta' within 1e-9 in >= 95 % of the records
+    and never off by more than a move along the fitted proposal (accept decisions on a knife edge)."""
     if kernel_mode != "auto":
-        pytest.skip("this test selects the two octet kernels itself")
+        pytest.skip("this test selects every form itself")
+    for k, v in SPLIT_FORMS[form].items():
+        monkeypatch.setenv(k, v)
     stem, data = model_spec(name)
-    C = 21
-    seeds = np.arange(C, dtype=np.uint64) + 8800
-    tol, sc = (1e-12, 600) if variant == 1 else (1e-10, 300)
-    fields = ("theta", "rng", "mean", "cov", "eigvecs", "eigvals", "om_m", "om_v", "pca_v", "grad_evals", "acc", "counters", "status", "kstate")
-    out = {}
-    monkeypatch.setenv("KLHR_CHUNK", "37")
-    for mode, mh in (("octet", ""), ("free", "exact"), ("free", "")):
-        monkeypatch.setenv("KLHR_KERNEL", mode)
-        monkeypatch.setenv("KLHR_FREE_MH", mh)
-        s = make_sampler(stem, data, C, warmup=100, variant=variant, overrelaxed=over, tol=tol, scale_clip=sc, **flags)
-        assert ("free" in s.kernel_name()) == (mode == "free"), s.kernel_name()
-        s.seed(seeds)
-        s.step(120, record_draws=True)
-        d = s.draws(0, 120)
-        s.step(7, record_diag=True)
-        out[(mode, mh)] = [d] + [s.get(f) for f in fields] + [s.get("diag"), s.get("rho"), s.get("eta")]
-    for a, b in zip(out[("octet", "")], out[("free", "exact")]):
-        assert np.array_equal(a, b, equal_nan=True)
-    a, b = out[("octet", "")], out[("free", "")]
-    ok = np.isfinite(a[0]).all(axis=(0, 2))
-    assert np.allclose(a[0][:, ok], b[0][:, ok], rtol=1e-9, atol=1e-9)
-    assert np.array_equal(a[2][ok], b[2][ok])          # the generator's position: same draws consumed, same decisions
+    kw = dict(warmup=100, scale_clip=3.0, grad_clip=3.0)
+    # ---- (a) free-running
+    C, n = 24, 49
+    seeds = np.arange(C, dtype=np.uint64) + 3100
+    ref = np.array([oracle.Chain(stem, data, seed=int(sd), **kw).draw_many(n) for sd in seeds]).transpose(1, 0, 2)
+    s = make_sampler(stem, data, C, **kw)
+    if form != "mono":
+        assert ("tile" in s.kernel_name()) == (form == "tile") and ("fitn" in s.kernel_name()) == (form == "fitn"), s.kernel_name()
+    s.seed(seeds)
+    s.step(n, record_draws=True)
+    got = s.draws(0, n)
+    err = np.abs(got - ref).max(axis=2)
+    first = np.array([np.argmax(err[:, c] > 1e-9) if (err[:, c] > 1e-9).any() else n for c in range(C)])
+    if stem != "ar1":
+        assert (first == n).sum() >= C - 2, (name, form, sorted(first))
+    else:
+        assert np.median(first) >= 4, (name, form, sorted(first))
+    assert not s.get("status").any()
+    # ---- (b) teacher-forced whole draws
+    recs = [oracle_state_trace(oracle, stem, data, seed=sd, n=60, **kw) for sd in (4200, 4201)]
+    M = sum(r["theta"].shape[0] for r in recs)
+    cat = lambda f: np.concatenate([r[f] for r in recs])
+    s = make_sampler(stem, data, M, **kw)
+    for f in STATE_FIELDS:
+        s.set(f, cat(f))
+    s.set("counters", cat("counters"))
+    s.set("acc", cat("acc_before"))
+    s.step(1)
+    assert np.array_equal(s.get("rng"), cat("rng_after"))
+    th, want = s.get("theta"), cat("theta_after")
+    e = np.abs(th - want).max(axis=1) / (1.0 + np.abs(want).max(axis=1))
+    assert np.mean(e < 1e-9) >= 0.95, (name, form, np.sort(e)[-8:])
+    moved = np.abs(want - cat("theta")).max(axis=1) + np.abs(th - cat("theta")).max(axis=1)
+    assert np.all(e <= 1e-9 + 2.0 * moved), (name, form)

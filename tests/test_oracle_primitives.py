@@ -61,6 +61,24 @@ def test_kl_and_models(oracle, name):
         assert close([f, df], g[f"{name}_line"][i], atol=1e-12 * max(1.0, np.abs(g[f"{name}_line"][i]).max())), i
 
 
+@pytest.mark.parametrize("name", ["funnel10", "illnormal100", "glmm45", "normal2", "funnel100", "ar1x100", "earnings"])
+def test_kl_with_the_gradient_clip_active(oracle, name):
+    """G4c: the reference's KL(eta, rho) with scale_clip = 3 — the element-wise clip of _logp_grad (klhr_sinh.py:158-161) bites at
+    nearly every quadrature node, on every target (ar1 included: G4 has none there)."""
+    g = golden("g4c_kl_clip.npz")
+    stem, data = model_spec(name)
+    c = oracle.Chain(stem, data, seed=11, scale_clip=float(g["scale_clip"][0]))
+    th, rho, eta = g[f"{name}_theta"], g[f"{name}_rho"], g[f"{name}_eta"]
+    assert (g[f"{name}_nclip"] > 0).sum() >= 59
+    for i in range(th.shape[0]):
+        c.set("theta", th[i])
+        v, gr = c.KL(eta[i], rho[i])
+        scale = max(1.0, abs(g[f"{name}_kl"][i])) if np.isfinite(g[f"{name}_kl"][i]) else 1.0
+        assert close(v, g[f"{name}_kl"][i], atol=1e-12 * scale), i
+        gs = np.abs(g[f"{name}_klgrad"][i]).max()
+        assert close(gr, g[f"{name}_klgrad"][i], atol=1e-12 * (gs if np.isfinite(gs) else 1.0)), i
+
+
 @pytest.mark.parametrize("name", ["funnel10", "illnormal100", "glmm45", "normal2", "ar1x100"])
 def test_model_gradients_finite_difference(oracle, name):
     """The closed forms stand in for BridgeStan (parity unpinned there): at least d/dtheta is self-consistent."""
