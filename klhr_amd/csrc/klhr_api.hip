@@ -241,6 +241,15 @@ static int dalloc(klhr_sampler *s, T **p, size_t n) {
     return 0;
 }
 
+// the direction cache follows eigvecs / eigvals / cov (split-pipeline handles; the streaming kernel's closure writes it itself)
+static int refresh_dircache(klhr_sampler *s) {
+    if (!s->kp.dir_m) return 0;
+    const int bs = 64;
+    hipLaunchKernelGGL(klhr_dircache_kernel, dim3((s->C + bs - 1) / bs), dim3(bs), 0, s->stream, s->kp);
+    HIPCHECK(s, hipGetLastError());
+    return 0;
+}
+
 static int reset_state(klhr_sampler *s) {
     KParams &k = s->kp;
     const size_t Cc = s->C, D = s->D, nc = s->ncol, J = s->cfg.J;
@@ -278,6 +287,7 @@ static int reset_state(klhr_sampler *s) {
         for (size_t c = 0; c < Cc; c++) { ks[c * 4 + 0] = (double)s->cfg.K; ks[c * 4 + 2] = (double)s->cfg.K; }
         HIPCHECK(s, hipMemcpyAsync(k.kstate, ks.data(), C * 4 * 8, hipMemcpyHostToDevice, s->stream));
     }
+    { int rc = refresh_dircache(s); if (rc) return rc; }
     HIPCHECK(s, hipStreamSynchronize(s->stream));
     return 0;
 }
@@ -397,6 +407,7 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
     k.draw_stride = (long long)s->C * D;
     if (s->split) {
         TRY(dalloc(s, &k.fitbuf, (size_t)F_NFIELDS * C));
+        TRY(dalloc(s, &k.dir_m, C * D)); TRY(dalloc(s, &k.dir_s, C * D));        // direction cache (KParams::dir_m)
         // few chains: the fit's latency (its slowest chain's sequence of passes) is the launch's duration — 8 lanes per chain
         // shorten the pass (klhr_split.hpp: klhr_fitn_kernel).  Measured, ill-normal-100, both stages: 16 384 chains 77 us against
         // 159, 32 768: 118 / 171, 65 536: 204 / 183, funnel-100 x 131 072: 952 / 676 — from 65 536 chains on lane = chain has the throughput
@@ -534,6 +545,7 @@ static bool group_view(const klhr_sampler *s, const KParams &kp, int g, int G, K
     out.rng += c0 * 4; out.counters += c0 * 4; out.kstate += c0 * 4; out.d_eta += c0 * 4;
     out.acc += c0; out.grad_evals += c0; out.status += c0; out.d_diag += c0 * KLHR_NDIAG;
     out.fitbuf += c0;
+    if (out.dir_m) { out.dir_m += c0 * D; out.dir_s += c0 * D; }
     if (out.draws) out.draws += c0 * D;
     return true;
 }
@@ -1009,6 +1021,10 @@ extern "C" int klhr_set_state(klhr_sampler *s, int field, const void *host_in, s
         const int bs = 64;
         hipLaunchKernelGGL(klhr_rank_kernel, dim3((s->C + bs - 1) / bs), dim3(bs), 0, s->stream, s->kp);
         HIPCHECK(s, hipGetLastError());
+    }
+    if (field == KLHR_F_COV || field == KLHR_F_EIGVECS || field == KLHR_F_EIGVALS) {
+        rc = refresh_dircache(s);
+        if (rc) return rc;
         HIPCHECK(s, hipStreamSynchronize(s->stream));
     }
     if (field == KLHR_F_RNG || field == KLHR_F_THETA) s->seeded = true;
@@ -1085,6 +1101,7 @@ extern "C" int klhr_pool_apply(klhr_sampler *s, const double *mean, const double
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { s->err = hipGetErrorString(e); rc = KLHR_ERR_HIP; }
     }
+    if (!rc) rc = refresh_dircache(s);
     if (!rc) rc = klhr_sync(s);
     (void)hipFree(d_m);
     return rc;
@@ -1243,6 +1260,7 @@ extern "C" int klhr_pool_apply_full(klhr_sampler *s, const double *mean, const d
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { s->err = hipGetErrorString(e); rc = KLHR_ERR_HIP; }
     }
+    if (!rc) rc = refresh_dircache(s);
     if (!rc) rc = klhr_sync(s);
     (void)hipFree(d_m);
     return rc;

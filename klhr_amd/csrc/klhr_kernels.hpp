@@ -69,6 +69,11 @@ struct KParams {
     long long fstride;           // field stride of fitbuf (the handle's padded chain count)
     long long draw_stride;       // doubles between two recorded iterations in `draws` (handle's chains x D)
     double *fitbuf;              // per-chain fit records, SoA [F_NFIELDS][fstride]
+    // window-constant pieces of the direction draw (klhr_sinh.py:207-211), refreshed wherever mean-direction inputs change (window
+    // closure, state setters, pooled adaptation): dir_m[i] = sum_j p_j eigvecs[i][j], dir_s[i] = sqrt(cov[i]) — the same operations in
+    // the same order as the per-draw code they replace, so the direction stays bit-exact.  Not used with eigen_method_one (the
+    // eigenvector is drawn anew for every direction).  nullptr for handles of the monolithic kernels.
+    double *dir_m, *dir_s;
     int stream_pair;             // streaming kernel: two wavefronts per tile (tail | head), narrow tiles (klhr_split.hpp)
     int stream_waves;            // streaming kernel: wavefronts (tiles) per workgroup, sharing one LDS copy of the ziggurat tables
 };
@@ -354,6 +359,27 @@ __device__ __forceinline__ void eval_objective(const KParams &p, const ModelData
 // ---- bit-exact (unfused, sequential) pieces: must round exactly like the NumPy expressions they restate
 #pragma clang fp contract(off)
 
+// The window-constant pieces of the direction draw for coordinate i of one chain (KParams::dir_m / dir_s): the mean
+// sum_j w_j eigvecs[i][j] (w = eigenvalue shares; klhr.py:150 weights by the raw eigenvalues) accumulated from 0 in column order, and
+// sqrt(cov[i]) — exactly what the direction pass computed per draw.  ev: the chain's eigenvalues; e: its eigenvector row.
+__device__ __forceinline__ void dir_weights(const KParams &p, const double *ev, double (&wj)[4]) {
+    const int nc = p.ncol;
+    double pj[4] = {0, 0, 0, 0};
+    double sum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (j < nc) sum += ev[j];
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (j < nc) pj[j] = ev[j] / sum;
+#pragma unroll
+    for (int j = 0; j < 4; j++) wj[j] = (p.variant == VAR_GAUSS || p.variant == VAR_SLICE) ? (j < nc ? ev[j] : 0.0) : pj[j];
+}
+__device__ __forceinline__ double dir_mean_elem(int nc, const double (&wj)[4], double e0, double e1, double e2) {
+    double m = 0;
+    m += wj[0] * e0;
+    if (nc > 1) m += wj[1] * e1;
+    if (nc > 2) m += wj[2] * e2;
+    return m;
+}
 // Lane-strided rows of the chain state: lane l8 of the octet owns elements l8, l8+8, ...  A row is fetched from HBM
 // OCT_CH elements at a time with all loads of the chunk in flight at once (a wavefront of this kernel is alone on its
 // SIMD most of the time: nothing else hides a load's latency).
@@ -1130,6 +1156,24 @@ __global__ void klhr_mh_kernel(const KParams p, double stepsize, int seed_only) 
 }
 
 #ifndef KLHR_HOT_TU
+// refresh of the direction cache (KParams::dir_m / dir_s) from eigvecs / eigvals / cov, one thread per chain: after the state
+// setters, the pooled-adaptation setters and klhr_seed (the closure inside the streaming kernel writes it itself)
+#pragma clang fp contract(off)
+__global__ void klhr_dircache_kernel(const KParams p) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= p.C || !p.dir_m) return;
+    const int D = p.D, nc = p.ncol;
+    double ev[4] = {0, 0, 0, 0}, wj[4];
+    for (int j = 0; j < 4; j++) if (j < nc) ev[j] = p.eigvals[c * nc + j];
+    dir_weights(p, ev, wj);
+    for (int i = 0; i < D; i++) {
+        const double e0 = p.eigvecs[kix2(p, c, i, 0, nc)], e1 = nc > 1 ? p.eigvecs[kix2(p, c, i, 1, nc)] : 0.0, e2 = nc > 2 ? p.eigvecs[kix2(p, c, i, 2, nc)] : 0.0;
+        p.dir_m[kix(p, c, i)] = dir_mean_elem(nc, wj, e0, e1, e2);
+        p.dir_s[kix(p, c, i)] = sqrt(p.cov[kix(p, c, i)]);
+    }
+}
+#pragma clang fp contract(fast)
+
 // rank permutation of cov after klhr_set_state(KLHR_F_COV)
 __global__ void klhr_rank_kernel(const KParams p) {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;

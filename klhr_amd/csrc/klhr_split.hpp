@@ -513,6 +513,7 @@ template <int N> struct Buf1 { static constexpr int n = N; double v[N]; };
 template <int N> struct Buf2 { static constexpr int n = N; double v[N], q[N]; };
 template <int N> struct BufT1 { static constexpr int n = N; double th[N], rr[N], mm[N], vv[N], mn[N]; };
 template <int N> struct BufDir { static constexpr int n = N; double e0[N], e1[N], e2[N], cv[N], th[N]; int rk[N]; };
+template <int N> struct BufDirC { static constexpr int n = N; double m[N], s[N], th[N]; int rk[N]; };
 
 #pragma clang fp contract(off)      // NumPy's element-wise roundings and summation orders (bit-exact pieces)
 
@@ -622,12 +623,24 @@ __device__ inline void split_close_window(const KParams &p, long long c, long lo
     }
 #pragma unroll
     for (int j = 0; j < 4; j++) { if (bad) vals[j] = 0.0; vals[j] += PCA_TOL; }
+    // (the direction cache of the next window: eigenvalue slots beyond K keep their previous values, as in the reference)
+    double evn[4] = {0, 0, 0, 0}, wj[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (j < nc) evn[j] = j < K ? vals[j] : p.eigvals[c * nc + j];
+    dir_weights(p, evn, wj);
+    const bool cache = p.dir_m != nullptr && !(p.flags & FLAG_EIGEN_ONE);
     for (int i = 0; i < D; i++) {
+        double e[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int j = 0; j < 4; j++) if (j < K) {
             const long long ev = tbv + ((long long)i * K + j) * W;
-            p.eigvecs[tbe + ((long long)i * nc + j) * W] = p.pca_v[ev] / vals[j];
+            e[j] = p.pca_v[ev] / vals[j];
+            p.eigvecs[tbe + ((long long)i * nc + j) * W] = e[j];
             p.pca_v[ev] = 0.0;
+        }
+        if (cache) {
+            p.dir_m[tb + (long long)i * W] = dir_mean_elem(nc, wj, e[0], e[1], e[2]);
+            p.dir_s[tb + (long long)i * W] = sqrt(Z[i * W]);          // Z still holds this closure's cov
         }
     }
 #pragma unroll
@@ -903,6 +916,31 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
         if (p.phases & PH_DIR) {
             if (role == 2) draw_normals();
             KLHR_STAMP(st_norm);
+            double n2 = 0;
+            const int *const rank = p.rank + tb;
+            if (p.dir_m != nullptr && !(p.flags & FLAG_EIGEN_ONE)) {
+                // the window-constant mean and sqrt(cov) come from the cache (written at the closure / by the state setters: the same
+                // operations in the same order): two rows to read instead of eigvecs' columns + cov, no sqrt and no weights per draw
+                const double *const dm = p.dir_m + tb, *const ds = p.dir_s + tb;
+                for_chunks_pipelined<ST_CH, BufDirC>(D,
+                    [&](auto &b, int i0) {
+#pragma unroll
+                        for (int k = 0; k < b.n; k++) {
+                            b.m[k] = dm[(i0 + k) * W]; b.s[k] = ds[(i0 + k) * W];
+                            b.rk[k] = rank[(i0 + k) * W]; b.th[k] = theta[(i0 + k) * W];
+                        }
+                    },
+                    [&](auto &b, int i0) {
+#pragma unroll
+                        for (int k = 0; k < b.n; k++) {
+                            const int i = i0 + k;
+                            const double r = b.m[k] + b.s[k] * Zn[b.rk[k] * W];
+                            n2 += (r + p.tol) * (r + p.tol);
+                            rho[i * W] = r;
+                            line_accumulate<MODEL>(p, i, b.th[k], r, st, Bs, Cs, m1, prev_th, prev_r);
+                        }
+                    });
+            } else {
             const double *ev = p.eigvals + c * nc;
             double pj[4] = {0, 0, 0, 0};
             double sum = 0;
@@ -925,9 +963,7 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
             double wj[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) wj[j] = pick >= 0 ? (j == pick ? 1.0 : 0.0) : ((VARIANT == VAR_GAUSS || VARIANT == VAR_SLICE) ? (j < nc ? ev[j] : 0.0) : pj[j]);
-            double n2 = 0;
             const double *const evec = p.eigvecs + tbe, *const cov = p.cov + tb;
-            const int *const rank = p.rank + tb;
             const long long es = (long long)nc * W;
             for_chunks_pipelined<ST_CH, BufDir>(D,
                 [&](auto &b, int i0) {
@@ -957,6 +993,7 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
                         line_accumulate<MODEL>(p, i, b.th[k], r, st, Bs, Cs, m1, prev_th, prev_r);
                     }
                 });
+            }
             nn = sqrt(n2);
         } else {
             // direction given in d_rho (klhr_fit / klhr_metropolis / probes of the C ABI): nn = 1
