@@ -40,5 +40,39 @@ for tag in DESC:
         txt += f"| `{tag}/` | `{row[0]}` | {row[1]} | {row[2]} | {row[3]} | {row[4]} | {row[5]} | {row[6]} |\n"
 s = open("profiles/README.md").read()
 i = s.index("\n\n## Round 2 (`r02_*`)"); j = s.index("\n`r02_stamps/`")
-open("profiles/README.md", "w").write(s[:i] + txt + s[j:])
+s = s[:i] + txt + s[j:]
+
+# ---- round 3: the four BASELINE configurations on the final build of the round, every traffic.json entry tied to its build id
+import json
+R3 = {"r03_lane_f10": "funnel-10 × 65 536 (headline), lane kernel", "r03_split_f100": "funnel-100 × 131 072, split pipeline (direction cache), `KLHR_GROUPS=1`",
+      "r03_split_ill": "ill-normal-100 × 16 384, split pipeline (pair-mode streaming, node-parallel fit), `KLHR_GROUPS=1`",
+      "r03_octet_glmm": "glmm-poisson-45 × 8 192, octet kernel"}
+tj = json.load(open("profiles/traffic.json"))
+t3 = "\n\n## Round 3 (`r03_*`): the four BASELINE configurations on the round's final build\n\n"
+t3 += ("Same commands as round 2 (`tools/profile_cfg.sh`, python directly after `rocprofv3 … --`).  New: every `traffic.json` entry carries `build_id` = `klhr_build_id()` "
+       "(sha256 of the library's sources) of the library it was measured on, and `bench.py` quotes `roofline.traffic` / `fp64_valu.measured` only while the loaded library is that "
+       "build (`traffic_stale: true` + reason otherwise); the entry's kernel is the one that moves the iteration's algorithmic bytes (streaming kernel / hot kernel), also when a fit "
+       "kernel is longer.  FETCH_SIZE ÷ 0.5 (tiled reads) or ÷ 1.40 (lane-private rows: mean of three calibration runs, 1.383 / 1.455 / 1.357, `r01b` / `r02_calibration` / "
+       "`r03_calibration`, which now also holds the `tile_write` WRITE_SIZE rows: 1.0000).  NOTE on register counts: rocprofv3's `VGPR_Count` column is (architectural + accumulation "
+       "registers) / 2 on this stack — the lane kernel's \"256\" is 256 + 256, `klhr_fit12_kernel`'s \"140\" is 256 + 18 (one wavefront per SIMD, as the compiler's resource remarks say); "
+       "round 2's DESIGN text read these columns as VGPR counts.  (This section is generated: `tools/profiles_readme.py`.)\n\n")
+t3 += "| dir | configuration | kernels: calls, average / minimum duration (µs), share |\n|---|---|---|\n"
+for tag, d in R3.items():
+    t3 += f"| `{tag}/` | {d} | " + "; ".join(f"`{n}` ×{c}: {a:.1f} / {m:.1f}, {p:.1f} %" for n, c, a, m, p in ks(tag)) + " |\n"
+t3 += ("\n| dir | kernel | VALU-active | waiting | lanes active | cycles / VALU | VALU / wavefront | (VGPR+AGPR)/2 / - / scratch |\n|---|---|---|---|---|---|---|---|\n")
+for tag in R3:
+    for row in sq(tag):
+        t3 += f"| `{tag}/` | `{row[0]}` | {row[1]} | {row[2]} | {row[3]} | {row[4]} | {row[5]} | {row[6]} |\n"
+t3 += "\n| `traffic.json` key | kernel | HBM bytes / launch (FETCH corrected + WRITE) | algorithmic bytes / launch | ratio | counter-derived fp64 GFLOP / launch | rocprof ms per iteration vs bench |\n|---|---|---|---|---|---|---|\n"
+for k, v in tj.items():
+    if "build_id" in v:
+        t3 += (f"| `{k}` | `{v['kernel'].replace('void klhr::', '')}` | {v['hbm_bytes_per_launch']/1e9:.3f} GB | {v['algorithmic_bytes_per_launch']/1e9:.3f} GB | "
+               f"{v['hbm_bytes_per_launch']/v['algorithmic_bytes_per_launch']:.2f} | {v['fp64_flops_per_launch']/1e9:.1f} | {v['rocprof_ms_per_iteration_all_kernels']:.4f} vs {v['bench_ms_per_step_when_profiled']:.4f} |\n")
+t3 += ("\n`r03_stamps/`: cycle split and bench of the free-running octet kernel (built, measured slower, removed: DESIGN.md §8).  `r03_experiments/`: `klhr_fit12_kernel` with a pass cap "
+       "(what the KL fits' tail costs) and with straggler compaction in several workgroup / register configurations, funnel-100 × 131 072, same box back to back.\n")
+k3 = "\n\n## Round 3 (`r03_*`)"
+if k3 in s:
+    s = s[:s.index(k3)]
+s = s.rstrip("\n") + t3
+open("profiles/README.md", "w").write(s)
 print("profiles/README.md regenerated")
