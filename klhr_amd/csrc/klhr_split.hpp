@@ -189,118 +189,6 @@ __device__ __forceinline__ void split_eval_kl(const KParams &p, const LineStat &
 }
 
 // ------------------------------------------------------------------------------------------------
-// The fit kernel for many chains: lane = chain (64 chains per wavefront, static), both stages of fit() one after the other in
-// ONE launch (klhr_fit12_kernel): the 1-D mode search with opt_advance<N = 1>, then the KL fit with opt_advance<N = 4 | 3 | 2>;
-// a lane's stage 2 reads back what its stage 1 wrote.  Every chain runs to completion (safety valve: KLHR_MAX_PASSES).
-// (Measured and removed in round 3, see DESIGN.md "dead ends": asynchronous chains with pass budgets, handing the long tail of
-//  the KL fits to a node-parallel resume kernel, fewer chains per fit wavefront — none of them gained beside the chain groups.)
-
-// Stage 1 of fit(): minimize(logp_grad_rho, x0, BFGS, gtol = 1e-5) (klhr_sinh.py:183-190)
-template <int MODEL>
-__device__ __forceinline__ void fit1_body(const KParams &p) {
-    const long long task = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
-    if (task >= p.C) return;
-    const bool diag = (p.flags & FLAG_DIAG) != 0;
-    Opt o;
-    const LineStat st = load_stat(p, task);
-    int npass = 0;
-    {
-        const double x0v[4] = {KLHR_FB(p, F_X0, task), 0, 0, 0};
-        if (diag) p.d_diag[task * KLHR_NDIAG + KLHR_D_X0] = x0v[0];
-        opt_begin(o, 1, x0v, 1e-5);
-    }
-    bool live = true;
-    while (__any(live)) {
-        if (live) {
-            double f = 0, g[4] = {0, 0, 0, 0};
-            if (opt_cache_hit(o)) { f = o.lf; g[0] = o.lg[0]; }
-            else {
-                double lp, gd;
-                (void)line_point<MODEL, false>(p, st, o.xt[0], INFINITY, lp, gd);
-                f = -lp; g[0] = -gd;
-                opt_cache_store(o, f, g);
-                npass++;
-            }
-            opt_advance<false, 1>(o, f, g);
-            const bool capped = npass > KLHR_MAX_PASSES;            // safety valve (klhr_kernels.hpp)
-            if (o.pc == PC_DONE || capped) {
-                double s = o.H[0];
-                s = (s > 0 ? 1.0 : 0.0) * 0.5 * log(s);
-                KLHR_FB(p, F_MODE, task) = o.xk[0];
-                KLHR_FB(p, F_INIT1, task) = s;
-                KLHR_FB(p, F_PASS, task) = (double)npass;
-                KLHR_FB(p, F_NFEV1, task) = (double)o.nfev;       // (stores only: a load here would stall the whole wavefront's pass)
-                if (capped && o.pc != PC_DONE) atomicOr(&p.status[task], 8);
-                if (diag) {
-                    double *dd = p.d_diag + task * KLHR_NDIAG;
-                    dd[KLHR_D_MODE] = o.xk[0]; dd[KLHR_D_HINV1] = o.H[0]; dd[KLHR_D_NFEV1] = o.nfev; dd[KLHR_D_NIT1] = o.k;
-                    dd[KLHR_D_STATUS1] = o.status; dd[KLHR_D_FALLBACKS] = o.fallbacks;
-                }
-                live = false;
-            }
-        }
-    }
-}
-
-// Stage 2 of fit(): minimize(KL, init, BFGS, gtol = 1e-3) (klhr_sinh.py:191-201; klhr.py:134-139; sub_klhr_sinh.py:184-192)
-template <int MODEL, int VARIANT>
-__device__ __forceinline__ void fit2_body(const KParams &p) {
-    constexpr int N = VARIANT == VAR_GAUSS ? 2 : (VARIANT == VAR_SUB ? 3 : 4);
-    const long long task = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
-    if (task >= p.C) return;
-    const bool diag = (p.flags & FLAG_DIAG) != 0;
-    Opt o;
-    const LineStat st = load_stat(p, task);
-    const double nn = KLHR_FB(p, F_NN, task);
-    int npass = 0;
-    const int npass1 = (int)KLHR_FB(p, F_PASS, task);
-    {
-        const double init[4] = {KLHR_FB(p, F_MODE, task), KLHR_FB(p, F_INIT1, task),
-                                VARIANT == VAR_GAUSS ? 0.0 : KLHR_FB(p, F_N2, task),
-                                VARIANT == VAR_SINH ? KLHR_FB(p, F_N3, task) : 0.0};
-        if (diag) {
-            double *dd = p.d_diag + task * KLHR_NDIAG;
-            dd[KLHR_D_INIT0] = init[0]; dd[KLHR_D_INIT1] = init[1]; dd[KLHR_D_INIT2] = init[2]; dd[KLHR_D_INIT3] = init[3];
-        }
-        opt_begin(o, N, init, VARIANT == VAR_GAUSS ? 1e-5 : 1e-3);
-    }
-    bool live = true;
-    while (__any(live)) {
-        if (live) {
-            double f = 0, g[4] = {0, 0, 0, 0};
-            if (opt_cache_hit(o)) { f = o.lf; g[0] = o.lg[0]; g[1] = o.lg[1]; g[2] = o.lg[2]; g[3] = o.lg[3]; }
-            else {
-                split_eval_kl<MODEL, VARIANT>(p, st, task, nn, o.xt, f, g);
-#ifdef KLHR_DBG_CHAIN
-                if (task == KLHR_DBG_CHAIN) printf("L pass %d x %a %a %a %a f %a g %a %a %a %a\n", npass, o.xt[0], o.xt[1], o.xt[2], o.xt[3], f, g[0], g[1], g[2], g[3]);
-#endif
-                opt_cache_store(o, f, g);
-                npass++;
-            }
-            opt_advance<false, N>(o, f, g);
-            const bool capped = npass > KLHR_MAX_PASSES;
-            if (o.pc == PC_DONE || capped) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) p.d_eta[task * 4 + k] = o.xk[k];
-                KLHR_FB(p, F_NFEV2, task) = (double)o.nfev;
-                if (capped && o.pc != PC_DONE) atomicOr(&p.status[task], 8);
-                if (diag) {
-                    double *dd = p.d_diag + task * KLHR_NDIAG;
-                    dd[KLHR_D_NFEV2] = o.nfev; dd[KLHR_D_NIT2] = o.k; dd[KLHR_D_STATUS2] = o.status; dd[KLHR_D_FUN2] = o.old_fval;
-                    dd[KLHR_D_FALLBACKS] += o.fallbacks; dd[KLHR_D_PASSES] = npass1 + npass;       // (diagnostic launches only)
-                }
-                live = false;
-            }
-        }
-    }
-}
-template <int MODEL, int VARIANT>
-__global__ __launch_bounds__(64) void klhr_fit12_kernel(const KParams p) {
-    fit1_body<MODEL>(p);
-    fit2_body<MODEL, VARIANT>(p);
-}
-
-// ------------------------------------------------------------------------------------------------
 // Node-parallel fit for FEW chains (klhr_split.hip: at most 16 384 per launch): both stages of fit() in one kernel, 8 lanes per
 // chain.  With lane = chain a launch lasts as long as its slowest chain's sequence of passes, however few chains there are,
 // and a KL pass is 8 quadrature nodes one after the other.  Here lane l8 of a chain's octet evaluates node l8 and a butterfly
@@ -445,6 +333,197 @@ template <int MODEL, int VARIANT>
 __global__ __launch_bounds__(64) void klhr_fitn_kernel(const KParams p) {
     const int lane = threadIdx.x & 63;
     fitn_body<MODEL, VARIANT>(p, (long long)blockIdx.x * 8 + (lane >> 3), lane & 7);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The fit kernel for MANY chains (klhr_fit12_kernel; above 32 768 chains): one wavefront = 64 chains, both stages of fit() in one
+// launch, in three steps:
+//   1. the 1-D mode search, lane = chain, opt_advance<N = 1> (klhr_sinh.py:183-190);
+//   2. the KL fit, lane = chain (8 quadrature nodes per lane, opt_advance<N = 4 | 3 | 2>), until at most FIT_THR = 8 of the wavefront's 64
+//      fits are still live.  The passes of a KL fit are narrowly distributed with a thin long tail (funnel-100: median 13, 90 % <= 14, 1 % >= 28,
+//      rare 60-75): run to completion in this form a wavefront lasts as long as its slowest chain (42 % of the lanes active on the round-2
+//      kernel; an experiment that capped every fit at 14 passes took the kernel from 0.62 to 0.35 ms);
+//   3. the stragglers: the <= 8 survivors leave their optimiser state, line sums and counters in LDS (80 doubles each) and are finished
+//      NODE-PARALLEL by the wavefront's 8 octets — lane l8 of an octet evaluates quadrature node l8, the butterfly hands every lane the same
+//      sums, the optimiser state is replicated in the 8 lanes (node_eval_kl, as in klhr_fitn_kernel): a pass of 8 lanes per chain has about
+//      a third of the latency of a lane = chain pass, and below ~16 live lanes it is also the cheaper form per chain.
+// Which form runs a pass has no influence on its arithmetic (the two forms return the same bits: tests/test_gpu_parity.py compares this kernel
+// with klhr_fitn_kernel and klhr_tile_kernel over populations, with the exact patch made a common path), nor has the lane a chain sits in.
+// Measured, funnel-100 x 131 072 (same box, back to back): kernel alone 0.62 -> 0.52 ms; the iteration with four overlapped chain groups
+// 1.46e8 -> 1.47e8 it/s — it is bound by the streaming kernel's LDS-limited concurrency, not by this kernel.
+constexpr int FIT_THR = 8, FITSLOT_DOUBLES = 80;
+// (element by element with constant indices: a struct copy would pin the optimiser state in scratch memory)
+__device__ __forceinline__ void fitslot_store(double *q, const Opt &o, const LineStat &st, double nn, long long task, int npass, int npass1) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) { q[k] = o.xk[k]; q[4 + k] = o.gfk[k]; q[8 + k] = o.pk[k]; q[12 + k] = o.xt[k]; q[16 + k] = o.lx[k]; q[20 + k] = o.lg[k]; }
+#pragma unroll
+    for (int k = 0; k < 16; k++) q[24 + k] = o.H[k];
+#pragma unroll
+    for (int k = 0; k < L_N; k++) q[40 + k] = o.ls[k];
+    q[53] = o.old_fval; q[54] = o.old_old_fval; q[55] = o.derphi0; q[56] = o.gtol; q[57] = o.areq; q[58] = o.lf;
+    q[59] = st.v0; q[60] = st.r0; q[61] = st.A; q[62] = st.B; q[63] = st.C; q[64] = st.m0; q[65] = st.m1; q[66] = nn;
+    q[67] = (double)task; q[68] = (double)npass; q[69] = (double)npass1;
+    q[70] = (double)o.n; q[71] = (double)o.k; q[72] = (double)o.nfev; q[73] = (double)o.status; q[74] = (double)o.fallbacks; q[75] = (double)o.pc;
+    q[76] = (double)o.it; q[77] = (double)o.i2; q[78] = (double)((o.have ? 1 : 0) | (o.brackt ? 2 : 0) | (o.stage2 ? 4 : 0));
+}
+__device__ __forceinline__ void fitslot_load(const double *q, Opt &o, LineStat &st, double &nn, long long &task, int &npass, int &npass1) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) { o.xk[k] = q[k]; o.gfk[k] = q[4 + k]; o.pk[k] = q[8 + k]; o.xt[k] = q[12 + k]; o.lx[k] = q[16 + k]; o.lg[k] = q[20 + k]; }
+#pragma unroll
+    for (int k = 0; k < 16; k++) o.H[k] = q[24 + k];
+#pragma unroll
+    for (int k = 0; k < L_N; k++) o.ls[k] = q[40 + k];
+    o.old_fval = q[53]; o.old_old_fval = q[54]; o.derphi0 = q[55]; o.gtol = q[56]; o.areq = q[57]; o.lf = q[58];
+    st.v0 = q[59]; st.r0 = q[60]; st.A = q[61]; st.B = q[62]; st.C = q[63]; st.m0 = q[64]; st.m1 = q[65]; nn = q[66];
+    task = (long long)q[67]; npass = (int)q[68]; npass1 = (int)q[69];
+    o.n = (int)q[70]; o.k = (int)q[71]; o.nfev = (int)q[72]; o.status = (int)q[73]; o.fallbacks = (int)q[74]; o.pc = (int)q[75];
+    o.it = (int)q[76]; o.i2 = (int)q[77];
+    const int fl = (int)q[78];
+    o.have = (fl & 1) != 0; o.brackt = (fl & 2) != 0; o.stage2 = (fl & 4) != 0;
+}
+
+// Stage 1 of fit(): minimize(logp_grad_rho, x0, BFGS, gtol = 1e-5) (klhr_sinh.py:183-190), lane = chain
+template <int MODEL>
+__device__ __forceinline__ void fit1_body(const KParams &p, const long long task, const bool active) {
+    const bool diag = (p.flags & FLAG_DIAG) != 0;
+    Opt o;
+    LineStat st = {0, 0, 0, 0, 0, 0, 0};
+    int npass = 0;
+    {
+        double x0v[4] = {0, 0, 0, 0};
+        if (active) {
+            st = load_stat(p, task);
+            x0v[0] = KLHR_FB(p, F_X0, task);
+            if (diag) p.d_diag[task * KLHR_NDIAG + KLHR_D_X0] = x0v[0];
+        }
+        opt_begin(o, 1, x0v, 1e-5);
+    }
+    bool live = active;
+    while (__any(live)) {
+        if (live) {
+            double f = 0, g[4] = {0, 0, 0, 0};
+            if (opt_cache_hit(o)) { f = o.lf; g[0] = o.lg[0]; }
+            else {
+                double lp, gd;
+                (void)line_point<MODEL, false>(p, st, o.xt[0], INFINITY, lp, gd);
+                f = -lp; g[0] = -gd;
+                opt_cache_store(o, f, g);
+                npass++;
+            }
+            opt_advance<false, 1>(o, f, g);
+            const bool capped = npass > KLHR_MAX_PASSES;            // safety valve (klhr_kernels.hpp)
+            if (o.pc == PC_DONE || capped) {
+                double s = o.H[0];
+                s = (s > 0 ? 1.0 : 0.0) * 0.5 * log(s);
+                KLHR_FB(p, F_MODE, task) = o.xk[0];
+                KLHR_FB(p, F_INIT1, task) = s;
+                KLHR_FB(p, F_PASS, task) = (double)npass;
+                KLHR_FB(p, F_NFEV1, task) = (double)o.nfev;       // (stores only: a load here would stall the whole wavefront's pass)
+                if (capped && o.pc != PC_DONE) atomicOr(&p.status[task], 8);
+                if (diag) {
+                    double *dd = p.d_diag + task * KLHR_NDIAG;
+                    dd[KLHR_D_MODE] = o.xk[0]; dd[KLHR_D_HINV1] = o.H[0]; dd[KLHR_D_NFEV1] = o.nfev; dd[KLHR_D_NIT1] = o.k;
+                    dd[KLHR_D_STATUS1] = o.status; dd[KLHR_D_FALLBACKS] = o.fallbacks;
+                }
+                live = false;
+            }
+        }
+    }
+}
+
+// the results of a finished KL fit (klhr_sinh.py:199-201): eta, evaluation count, status, diagnostics
+__device__ __forceinline__ void fit2_finish(const KParams &p, const Opt &o, const long long task, const int npass, const int npass1, const bool diag) {
+    KLHR_FB(p, F_NFEV2, task) = (double)o.nfev;
+    if (o.pc != PC_DONE) atomicOr(&p.status[task], 8);
+    if (diag) {
+        double *dd = p.d_diag + task * KLHR_NDIAG;
+        dd[KLHR_D_NFEV2] = o.nfev; dd[KLHR_D_NIT2] = o.k; dd[KLHR_D_STATUS2] = o.status; dd[KLHR_D_FUN2] = o.old_fval;
+        dd[KLHR_D_FALLBACKS] += o.fallbacks; dd[KLHR_D_PASSES] = npass1 + npass;       // (diagnostic launches only)
+    }
+}
+
+template <int MODEL, int VARIANT>
+__global__ __launch_bounds__(64) void klhr_fit12_kernel(const KParams p) {
+    constexpr int N = VARIANT == VAR_GAUSS ? 2 : (VARIANT == VAR_SUB ? 3 : 4);
+    __shared__ double slots[FIT_THR * FITSLOT_DOUBLES];
+    const int lane = threadIdx.x & 63, l8 = lane & 7;
+    long long task = (long long)blockIdx.x * 64 + lane;
+    const bool active = task < p.C;
+    const bool diag = (p.flags & FLAG_DIAG) != 0;
+    // ---- 1. mode search
+    fit1_body<MODEL>(p, task, active);
+    // ---- 2. KL fit, lane = chain, until at most FIT_THR of this wavefront's fits are live
+    Opt o;
+    LineStat st = {0, 0, 0, 0, 0, 0, 0};
+    double nn = 1.0;
+    int npass = 0, npass1 = 0;
+    {
+        double init[4] = {0, 0, 0, 0};
+        if (active) {
+            st = load_stat(p, task);
+            nn = KLHR_FB(p, F_NN, task);
+            npass1 = (int)KLHR_FB(p, F_PASS, task);
+            init[0] = KLHR_FB(p, F_MODE, task); init[1] = KLHR_FB(p, F_INIT1, task);
+            init[2] = VARIANT == VAR_GAUSS ? 0.0 : KLHR_FB(p, F_N2, task);
+            init[3] = VARIANT == VAR_SINH ? KLHR_FB(p, F_N3, task) : 0.0;
+            if (diag) {
+                double *dd = p.d_diag + task * KLHR_NDIAG;
+                dd[KLHR_D_INIT0] = init[0]; dd[KLHR_D_INIT1] = init[1]; dd[KLHR_D_INIT2] = init[2]; dd[KLHR_D_INIT3] = init[3];
+            }
+        }
+        opt_begin(o, N, init, VARIANT == VAR_GAUSS ? 1e-5 : 1e-3);
+    }
+    bool live = active;
+    while (__popcll(__ballot(live)) > FIT_THR) {
+        if (live) {
+            double f = 0, g[4] = {0, 0, 0, 0};
+            if (opt_cache_hit(o)) { f = o.lf; g[0] = o.lg[0]; g[1] = o.lg[1]; g[2] = o.lg[2]; g[3] = o.lg[3]; }
+            else {
+                split_eval_kl<MODEL, VARIANT>(p, st, task, nn, o.xt, f, g);
+#ifdef KLHR_DBG_CHAIN
+                if (task == KLHR_DBG_CHAIN) printf("L pass %d x %a %a %a %a f %a g %a %a %a %a\n", npass, o.xt[0], o.xt[1], o.xt[2], o.xt[3], f, g[0], g[1], g[2], g[3]);
+#endif
+                opt_cache_store(o, f, g);
+                npass++;
+            }
+            opt_advance<false, N>(o, f, g);
+            if (o.pc == PC_DONE || npass > KLHR_MAX_PASSES) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) p.d_eta[task * 4 + k] = o.xk[k];
+                fit2_finish(p, o, task, npass, npass1, diag);
+                live = false;
+            }
+        }
+    }
+    // ---- 3. the stragglers: records through LDS (wave-level synchronisation: the workgroup is this wavefront), then node-parallel
+    const unsigned long long m = __ballot(live);
+    const int n = __popcll(m);
+    if (n == 0) return;
+    if (live) fitslot_store(slots + (size_t)__popcll(m & ((1ull << lane) - 1ull)) * FITSLOT_DOUBLES, o, st, nn, task, npass, npass1);
+    KLHR_WAVE_SYNC();
+    // this lane's quadrature node (a per-lane index into the kernel-argument tables would go through scratch)
+    double q_a = p.asx[0], q_x = p.xq[0], q_w = p.wq[0];
+#pragma unroll
+    for (int k = 1; k < 8; k++) if (l8 == k) { q_a = p.asx[k]; q_x = p.xq[k]; q_w = p.wq[k]; }
+    live = (lane >> 3) < n;                        // (whole octets: the butterflies stay inside an octet)
+    if (live) fitslot_load(slots + (size_t)(lane >> 3) * FITSLOT_DOUBLES, o, st, nn, task, npass, npass1);
+    while (__any(live)) {
+        if (live) {
+            double f = 0, g[4] = {0, 0, 0, 0};
+            if (opt_cache_hit(o)) { f = o.lf; g[0] = o.lg[0]; g[1] = o.lg[1]; g[2] = o.lg[2]; g[3] = o.lg[3]; }
+            else {
+                node_eval_kl<MODEL, VARIANT>(p, st, task, nn, o.xt, q_a, q_x, q_w, f, g);
+                opt_cache_store(o, f, g);
+                npass++;
+            }
+            opt_advance<false, N>(o, f, g);
+            if (o.pc == PC_DONE || npass > KLHR_MAX_PASSES) {
+                if (l8 < 4) p.d_eta[task * 4 + l8] = l8 == 0 ? o.xk[0] : (l8 == 1 ? o.xk[1] : (l8 == 2 ? o.xk[2] : o.xk[3]));
+                if (l8 == 0) fit2_finish(p, o, task, npass, npass1, diag);
+                live = false;
+            }
+        }
+    }
 }
 
 // KL / line probes of the C ABI (klhr_kl_eval, klhr_line_eval): one evaluation per chain at eta = d_eta
