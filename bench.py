@@ -36,6 +36,7 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak (half of the 157.3 TF fp32 vector rate)
 SETUP_DRAWS = 150              # untimed: the sampler's warmup = 100 draws (both windows close) + 50
 REPEATS = 5
+POOLED_TIMEOUT_S = 240           # N > 1: the pooled shard (RCCL) gets this long before the watchdog reports and gives up
 
 
 def algorithmic_bytes_per_iter(D, J=2):
@@ -360,7 +361,18 @@ def main():
         out["pooled"] = res["pooled"]
     rccl_failed = None
     if world > 1 and not args.no_configs:
-        # every rank takes part (the collective needs them all); rank 0 reports
+        # every rank takes part (the collective needs them all); rank 0 reports.  A collective that never returns must not take the
+        # headline with it: a watchdog prints the line measured so far (with rccl.error) and ends the process with a non-zero code.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["rccl"] = {"error": f"the pooled shard (RCCL communicator / all-reduce over {world} ranks) did not finish within {POOLED_TIMEOUT_S} s"}
+                print(json.dumps(out), flush=True)
+            os._exit(3)
+        watchdog = threading.Timer(POOLED_TIMEOUT_S, give_up)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             pr, pd = pooled_shard(rank, world, device, args.seed, dist)
             pc = pr["pooled"]
@@ -376,6 +388,7 @@ def main():
         except Exception as e:          # reported in the line AND through the exit code
             rccl_failed = f"{type(e).__name__}: {e}"
             out["rccl"] = {"error": rccl_failed}
+        watchdog.cancel()
     if rank == 0:
         if not args.no_ess:
             if headline:
