@@ -158,6 +158,48 @@ def test_ess_estimator_on_ar1():
     assert 0.8 * 16000 < ess(iid) < 1.3 * 16000
 
 
+def test_ess_detail_reports_tau_lag_and_a_saturated_window():
+    """ess_detail: tau and the truncation lag of a resolved chain; a chain whose autocorrelation time exceeds the run leaves the
+    truncation at the end of the window (what bench.py refuses to quote); the between-chain tau bench.py cross-checks with."""
+    from klhr_amd.ess import ess_detail
+    rng = np.random.default_rng(3)
+    M, C, phi = 20000, 64, 0.9
+    x = np.zeros((M, C))
+    x[0] = rng.normal(size=C) / np.sqrt(1 - phi * phi)
+    e = rng.normal(size=(M, C))
+    for t in range(1, M):
+        x[t] = phi * x[t - 1] + e[t]
+    d = ess_detail(x)
+    tau_exact = (1 + phi) / (1 - phi)
+    assert 0.85 * tau_exact < d["tau"] < 1.15 * tau_exact and d["truncation_lag"] < M / 10 and abs(d["rhat"] - 1) < 0.01
+    tau_between = M * x.mean(axis=0).var(ddof=1) / x.var()
+    assert 0.6 * tau_exact < tau_between < 1.5 * tau_exact                 # (64 chains: +-18 %)
+    slow = np.cumsum(rng.normal(size=(500, 8)), axis=0)                    # random walks: tau >= run length
+    ds = ess_detail(slow)
+    assert ds["truncation_lag"] >= 500 / 10
+
+
+def test_pooled_diag_is_the_diagonal_of_pooled_full():
+    from klhr_amd.parallel import pooled_diag, pooled_full
+    rng = np.random.default_rng(5)
+    X = rng.normal(size=(300, 6)) * np.arange(1, 7)
+    stats = np.concatenate([[X.shape[0]], X.sum(axis=0), (X.T @ X).reshape(-1)])
+    m, v = pooled_diag(stats, 6)
+    fm, fd, _, _ = pooled_full(stats, 6, 2)
+    assert np.allclose(m, X.mean(axis=0), rtol=1e-13) and np.allclose(v, X.var(axis=0, ddof=1), rtol=1e-11)
+    assert np.allclose(m, fm, rtol=0, atol=0) and np.allclose(v, fd, rtol=1e-12)
+
+
+def test_traffic_entries_are_tied_to_a_build():
+    """every round-3 entry of profiles/traffic.json names the library build it was measured on (bench.py quotes it for that build only)"""
+    import json
+    from klhr_amd import build
+    t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    keys = ["funnel-10-65536", "ill-normal-100-16384", "glmm-poisson-45-8192", "funnel-100-131072"]
+    assert all(len(t[k].get("build_id", "")) == 64 for k in keys)
+    assert len(build.source_hash()) == 64
+
+
 def test_roofline_byte_model():
     import bench
     assert bench.algorithmic_bytes_per_iter(10) == 1328          # SURVEY.md §8d
