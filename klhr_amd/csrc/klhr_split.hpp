@@ -554,11 +554,16 @@ __global__ __launch_bounds__(64) void klhr_probe_kernel(const KParams p) {
 // wavefronts — more loads in flight — on the machine when there are few chains.
 // A row is walked CH elements at a time: all loads of a chunk are issued before the first use, whole chunks carry no bounds
 // checks (one base address per array and chunk, immediate offsets k*W*8), the D % CH remaining elements go one by one.
-template <int CH, class F>
-__device__ __forceinline__ void for_chunks(int D, F f) {
-    int i0 = 0;
-    for (; i0 + CH <= D; i0 += CH) f(std::integral_constant<int, CH>(), i0);
-    for (; i0 < D; ++i0) f(std::integral_constant<int, 1>(), i0);
+// (quad mode, QN = 4: lane q of a chain's quad takes the elements q, q + 4, ... one at a time — element-wise work only)
+template <int CH, int QN = 1, class F>
+__device__ __forceinline__ void for_chunks(int D, int q, F f) {
+    if constexpr (QN == 1) {
+        int i0 = 0;
+        for (; i0 + CH <= D; i0 += CH) f(std::integral_constant<int, CH>(), i0);
+        for (; i0 < D; ++i0) f(std::integral_constant<int, 1>(), i0);
+    } else {
+        for (int i = q; i < D; i += QN) f(std::integral_constant<int, 1>(), i);
+    }
 }
 #ifndef KLHR_ST_CH
 #define KLHR_ST_CH 8
@@ -566,27 +571,70 @@ __device__ __forceinline__ void for_chunks(int D, F f) {
 #ifndef KLHR_ST_CH1
 #define KLHR_ST_CH1 16
 #endif
+#ifndef KLHR_ST_QDIV
+#define KLHR_ST_QDIV 4
+#endif
 // (inside functions templated on the tile width W.  16-chain tiles: half the chunk — measured the same speed, and the
 //  streaming kernel then fits 256 registers, i.e. two wavefronts per SIMD, which its pair mode needs)
-#define ST_CH (W == 16 ? KLHR_ST_CH / 2 : KLHR_ST_CH)          // passes over several arrays
-#define ST_CH1 (W == 16 ? KLHR_ST_CH1 / 2 : KLHR_ST_CH1)       // passes over one or two arrays
+#define ST_CH (W == 16 ? KLHR_ST_CH / KLHR_ST_QDIV : KLHR_ST_CH)          // passes over several arrays
+#define ST_CH1 (W == 16 ? KLHR_ST_CH1 / KLHR_ST_QDIV : KLHR_ST_CH1)       // passes over one or two arrays
 
-// Software-pipelined form: `load(buf, i0)` fills a register buffer with the chunk at i0, `compute(buf, i0)` consumes it.
-// The loads of chunk j+1 are issued before chunk j is computed (two buffers): a wavefront of this kernel has at most one
-// or two neighbours on its SIMD (the LDS column scratch bounds the occupancy), so it hides its own memory latency.
-template <int CH, template <int> class BUF, class L, class C>
+// Software-pipelined form: `load(buf, s0, full)` fills a register buffer with the chunk of CH steps at s0, `compute(buf, s0,
+// full)` consumes it.  The loads of chunk j+1 are issued before chunk j is computed (two buffers): a wavefront of this kernel
+// has at most one or two neighbours on its SIMD (the LDS column scratch bounds the occupancy), so it hides its own memory latency.
+// A step is QN coordinates (lane = chain: 1; quad mode: 4, one per lane of the chain's quad — element (s0 + k) * QN + q);
+// `full` is std::true_type for whole steps; quad mode ends with one std::false_type step when D % 4 != 0 (some lanes past D).
+template <int CH, template <int> class BUF, int QN, class L, class C>
 __device__ __forceinline__ void for_chunks_pipelined(int D, L load, C compute) {
+    const int NS = D / QN;
+    const std::true_type full;
     BUF<CH> a, b;
-    int i0 = 0;
-    if (CH <= D) load(a, 0);
-    for (; i0 + 2 * CH <= D; i0 += 2 * CH) {
-        load(b, i0 + CH);
-        compute(a, i0);
-        if (i0 + 3 * CH <= D) load(a, i0 + 2 * CH);
-        compute(b, i0 + CH);
+    int s0 = 0;
+    if (CH <= NS) load(a, 0, full);
+    for (; s0 + 2 * CH <= NS; s0 += 2 * CH) {
+        load(b, s0 + CH, full);
+        compute(a, s0, full);
+        if (s0 + 3 * CH <= NS) load(a, s0 + 2 * CH, full);
+        compute(b, s0 + CH, full);
     }
-    if (i0 + CH <= D) { compute(a, i0); i0 += CH; }
-    for (; i0 < D; ++i0) { BUF<1> r; load(r, i0); compute(r, i0); }
+    if (s0 + CH <= NS) { compute(a, s0, full); s0 += CH; }
+    for (; s0 < NS; ++s0) { BUF<1> r; load(r, s0, full); compute(r, s0, full); }
+    if (QN > 1 && NS * QN < D) { BUF<1> r; load(r, NS, std::false_type()); compute(r, NS, std::false_type()); }
+}
+
+// ---- QUAD MODE (16-chain tiles): lane = (chain cl = lane >> 2, phase q = lane & 3) — the four lanes of a DPP quad walk one
+// chain's rows four coordinates per step (element i = 4 step + q; a row segment of a tile is still 16 chains x 4 coordinates =
+// 512 contiguous bytes).  A 16-chain tile with lane = chain leaves 48 of the wavefront's 64 lanes idle at full instruction
+// cost; here the element-wise arithmetic (theta', OnlineMoments, CCIPCA's updates, the direction) costs a quarter of the
+// instructions.  The sums whose order NumPy fixes stay sequential in the coordinate index: the four lanes' terms are broadcast
+// over the quad (two v_mov_b32 quad_perm per double) and every lane adds them in index order — identical bits in all four
+// lanes, and identical to lane = chain.  Per-chain scalars (generator, MH, counters) are replicated in the quad.
+template <int Q>
+__device__ __forceinline__ double quad_bcast(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, Q * 0x55, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, Q * 0x55, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// lane q <- lane q - 1 of the quad (lane 0 keeps its own value: the caller substitutes the previous step's last element)
+__device__ __forceinline__ double quad_prev(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x90, 0xf, 0xf, false);      // quad_perm:[0,0,1,2]
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x90, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// f(i, v...) for the elements of one step in index order: lane = chain calls it once with the lane's own values; quad mode four
+// times, with the values of quad lane 0, 1, 2, 3 (elements past D are skipped: `step` and D are wavefront-uniform)
+template <int QN, bool FULL, class F, class... T>
+__device__ __forceinline__ void seq_each(int step, int D, F f, T... v) {
+    if constexpr (QN == 1) f(step, v...);
+    else {
+        const int i0 = step * 4;
+        f(i0, quad_bcast<0>(v)...);
+        if (FULL || i0 + 1 < D) f(i0 + 1, quad_bcast<1>(v)...);
+        if (FULL || i0 + 2 < D) f(i0 + 2, quad_bcast<2>(v)...);
+        if (FULL || i0 + 3 < D) f(i0 + 3, quad_bcast<3>(v)...);
+    }
 }
 template <int N> struct Buf1 { static constexpr int n = N; double v[N]; };
 template <int N> struct Buf2 { static constexpr int n = N; double v[N], q[N]; };
@@ -596,11 +644,12 @@ template <int N> struct BufDirC { static constexpr int n = N; double m[N], s[N],
 
 #pragma clang fp contract(off)      // NumPy's element-wise roundings and summation orders (bit-exact pieces)
 
-// onlinepca.py:13-26 for the chain of this lane.  u = theta - mean in Z (LDS column of the lane, stride W), V = the tile's
+// onlinepca.py:13-26 for the chain of this lane (quad).  u = theta - mean in Z (LDS column of the chain, stride W), V = the tile's
 // pca_v rows.  Per component: sums (s, u.v) -> v' = w v + (1-w) u (u.v)/(|v|+tol), sums on v' -> u -= (u.v') v'/(|v'|^2+tol);
-// the deflation pass of component j also gathers the first sums of component j+1.
+// the deflation pass of component j also gathers the first sums of component j+1.  q: the lane's phase in quad mode (0 otherwise).
 template <int W>
-__device__ inline void split_pca_update(const KParams &p, double *V, long long n_new, double *Z) {
+__device__ inline void split_pca_update(const KParams &p, double *V, long long n_new, double *Z, const int q) {
+    constexpr int QN = W == 16 ? 4 : 1;
     const int D = p.D, K = p.J;
     const long long lim = n_new < K ? n_new : K;
     const long long vs = (long long)K * W;
@@ -609,36 +658,42 @@ __device__ inline void split_pca_update(const KParams &p, double *V, long long n
     for (int col = 0; col < lim; col++) {
         double *Vc = V + (long long)col * W;
         if (col == n_new - 1) {
-            for (int i = 0; i < D; i++) Vc[i * vs] = Z[i * W];
+            for (int i = q; i < D; i += QN) Vc[i * vs] = Z[i * W];
             have_sums = false;
         } else {
             const double w = ((double)(n_new - 1) - p.l) / (double)n_new;
             if (!have_sums) {
                 s = 0; udv = 0;
-                for_chunks_pipelined<ST_CH1, Buf1>(D,
-                    [&](auto &b, int i0) {
+                for_chunks_pipelined<ST_CH1, Buf1, QN>(D,
+                    [&](auto &b, int s0, auto full) {
 #pragma unroll
-                        for (int k = 0; k < b.n; k++) b.v[k] = Vc[(i0 + k) * vs];
+                        for (int k = 0; k < b.n; k++) { const int i = (s0 + k) * QN + q; b.v[k] = Vc[(full || i < D ? i : D - 1) * vs]; }
                     },
-                    [&](auto &b, int i0) {
+                    [&](auto &b, int s0, auto full) {
 #pragma unroll
-                        for (int k = 0; k < b.n; k++) { s += b.v[k] * b.v[k]; udv += Z[(i0 + k) * W] * b.v[k]; }
+                        for (int k = 0; k < b.n; k++) {
+                            const int i = (s0 + k) * QN + q;
+                            const double z = Z[(full || i < D ? i : D - 1) * W];
+                            seq_each<QN, decltype(full)::value>(s0 + k, D, [&](int, double vv, double zv) { s += vv; udv += zv; }, b.v[k] * b.v[k], z * b.v[k]);
+                        }
                     });
             }
             const double nv = sqrt(s);
             double s2 = 0, udv2 = 0;
-            for_chunks_pipelined<ST_CH1, Buf1>(D,
-                [&](auto &b, int i0) {
+            for_chunks_pipelined<ST_CH1, Buf1, QN>(D,
+                [&](auto &b, int s0, auto full) {
 #pragma unroll
-                    for (int k = 0; k < b.n; k++) b.v[k] = Vc[(i0 + k) * vs];
+                    for (int k = 0; k < b.n; k++) { const int i = (s0 + k) * QN + q; b.v[k] = Vc[(full || i < D ? i : D - 1) * vs]; }
                 },
-                [&](auto &b, int i0) {
+                [&](auto &b, int s0, auto full) {
 #pragma unroll
                     for (int k = 0; k < b.n; k++) {
-                        const double z = Z[(i0 + k) * W];
+                        const int i = (s0 + k) * QN + q;
+                        const bool valid = full || i < D;
+                        const double z = Z[(valid ? i : D - 1) * W];
                         const double vn = w * b.v[k] + (1 - w) * z * udv / (nv + PCA_TOL);
-                        Vc[(i0 + k) * vs] = vn;
-                        s2 += vn * vn; udv2 += z * vn;
+                        if (valid) Vc[i * vs] = vn;
+                        seq_each<QN, decltype(full)::value>(s0 + k, D, [&](int, double vv, double zv) { s2 += vv; udv2 += zv; }, vn * vn, z * vn);
                     }
                 });
             have_sums = false;
@@ -647,17 +702,23 @@ __device__ inline void split_pca_update(const KParams &p, double *V, long long n
                 const bool next_sums = col + 1 != n_new - 1;       // the next component is updated, not assigned
                 const double *Vn = V + (long long)(col + 1) * W;
                 s = 0; udv = 0;
-                for_chunks_pipelined<ST_CH, Buf2>(D,
-                    [&](auto &b, int i0) {
-#pragma unroll
-                        for (int k = 0; k < b.n; k++) { b.v[k] = Vc[(i0 + k) * vs]; b.q[k] = next_sums ? Vn[(i0 + k) * vs] : 0.0; }
-                    },
-                    [&](auto &b, int i0) {
+                for_chunks_pipelined<ST_CH, Buf2, QN>(D,
+                    [&](auto &b, int s0, auto full) {
 #pragma unroll
                         for (int k = 0; k < b.n; k++) {
-                            const double z = Z[(i0 + k) * W] - udv2 * b.v[k] / (nv2 * nv2 + PCA_TOL);
-                            Z[(i0 + k) * W] = z;
-                            if (next_sums) { s += b.q[k] * b.q[k]; udv += z * b.q[k]; }
+                            const int i = (s0 + k) * QN + q;
+                            const int ic = full || i < D ? i : D - 1;
+                            b.v[k] = Vc[ic * vs]; b.q[k] = next_sums ? Vn[ic * vs] : 0.0;
+                        }
+                    },
+                    [&](auto &b, int s0, auto full) {
+#pragma unroll
+                        for (int k = 0; k < b.n; k++) {
+                            const int i = (s0 + k) * QN + q;
+                            const bool valid = full || i < D;
+                            const double z = Z[(valid ? i : D - 1) * W] - udv2 * b.v[k] / (nv2 * nv2 + PCA_TOL);
+                            if (valid) Z[i * W] = z;
+                            if (next_sums) seq_each<QN, decltype(full)::value>(s0 + k, D, [&](int, double vv, double zv) { s += vv; udv += zv; }, b.q[k] * b.q[k], z * b.q[k]);
                         }
                     });
                 have_sums = next_sums;
@@ -666,11 +727,13 @@ __device__ inline void split_pca_update(const KParams &p, double *V, long long n
     }
 }
 
-// klhr_sinh.py:268-280 (+ the rank permutation multivariate_normal's SVD applies to the following windows' normals)
+// klhr_sinh.py:268-280 (+ the rank permutation multivariate_normal's SVD applies to the following windows' normals).
+// Quad mode: lane q of the chain's quad closes the coordinates i = q, q + 4, ...; the column norms are summed in index order.
 template <int W>
-__device__ inline void split_close_window(const KParams &p, long long c, long long tb, long long tbe, long long tbv, long long omN, double *Z) {
+__device__ inline void split_close_window(const KParams &p, long long c, long long tb, long long tbe, long long tbv, long long omN, double *Z, const int q) {
+    constexpr int QN = W == 16 ? 4 : 1;
     const int D = p.D, K = p.J, nc = p.ncol;
-    for (int i = 0; i < D; i++) {
+    for (int i = q; i < D; i += QN) {
         const long long e = tb + (long long)i * W;
         p.mean[e] = p.om_m[e];
         double cv = omN > 2 ? p.om_v[e] * (double)omN / (double)(omN - 1) : 1.0;
@@ -683,7 +746,8 @@ __device__ inline void split_close_window(const KParams &p, long long c, long lo
         Z[i * W] = cv;
         p.om_m[e] = 0.0; p.om_v[e] = 0.0;
     }
-    for (int i = 0; i < D; i++) {
+    if (QN > 1) KLHR_WAVE_SYNC();          // the ranks read every coordinate's cov, written by the quad's four lanes
+    for (int i = q; i < D; i += QN) {
         const double ci = Z[i * W];
         int r = 0;
         for (int j = 0; j < D; j++) { const double cj = Z[j * W]; r += (cj > ci || (cj == ci && j < i)) ? 1 : 0; }
@@ -695,7 +759,11 @@ __device__ inline void split_close_window(const KParams &p, long long c, long lo
     for (int j = 0; j < 4; j++) {
         if (j < K) {
             double s = 0;
-            for (int i = 0; i < D; i++) { const double vi = p.pca_v[tbv + ((long long)i * K + j) * W]; s += vi * vi; }
+            for (int s0 = 0; s0 * QN < D; s0++) {
+                const int i = s0 * QN + q;
+                const double vi = p.pca_v[tbv + ((long long)(i < D ? i : D - 1) * K + j) * W];
+                seq_each<QN, false>(s0, D, [&](int, double vv) { s += vv; }, vi * vi);
+            }
             vals[j] = sqrt(s);
             if (!isfinite(vals[j])) bad = true;
         }
@@ -708,7 +776,7 @@ __device__ inline void split_close_window(const KParams &p, long long c, long lo
     for (int j = 0; j < 4; j++) if (j < nc) evn[j] = j < K ? vals[j] : p.eigvals[c * nc + j];
     dir_weights(p, evn, wj);
     const bool cache = p.dir_m != nullptr && !(p.flags & FLAG_EIGEN_ONE);
-    for (int i = 0; i < D; i++) {
+    for (int i = q; i < D; i += QN) {
         double e[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int j = 0; j < 4; j++) if (j < K) {
@@ -722,8 +790,11 @@ __device__ inline void split_close_window(const KParams &p, long long c, long lo
             p.dir_s[tb + (long long)i * W] = sqrt(Z[i * W]);          // Z still holds this closure's cov
         }
     }
+    if (QN > 1) KLHR_WAVE_SYNC();          // (eigvals of slots >= K were read above by every lane of the quad)
+    if (q == 0) {
 #pragma unroll
-    for (int j = 0; j < 4; j++) if (j < K) p.eigvals[c * nc + j] = vals[j];
+        for (int j = 0; j < 4; j++) if (j < K) p.eigvals[c * nc + j] = vals[j];
+    }
 }
 
 // (still contract(off): the streaming kernel's own arithmetic — accept/reject blend, OnlineMoments, direction draw — is
@@ -761,6 +832,28 @@ __device__ __forceinline__ void line_accumulate(const KParams &p, int i, double 
     }
 }
 
+// Quad mode: the element-wise half of line_accumulate for the lane's own coordinate i (pth, pr: coordinate i - 1, ar1 only) —
+// a, rs enter the three fma chains in index order (seq_each), am, rm the maxima (order-free: a per-lane maximum, reduced over
+// the quad after the pass; a NaN coordinate makes m0 NaN)
+template <int MODEL>
+__device__ __forceinline__ void line_elem(const KParams &p, int i, double th, double r, double pth, double pr, double &a, double &rs, double &am,
+                                          double &rm) {
+    a = th; rs = r;
+    double is = 1.0;
+    if constexpr (MODEL == MODEL_ILL_NORMAL) { is = p.md.aux[i]; a = a * is; rs = rs * is; }
+    if constexpr (MODEL == MODEL_AR1) {
+        const double ca = 0.9, cb = sqrt(1 - ca * ca);
+        if (i > 0) { a = (th - ca * pth) / cb; rs = (r - ca * pr) / cb; }
+    }
+    double a2 = a, r2 = rs;
+    if constexpr (MODEL == MODEL_ILL_NORMAL) { a2 = a2 * is; r2 = r2 * is; }
+    if constexpr (MODEL == MODEL_AR1) { const double kap = 1.9 / sqrt(1 - 0.81); a2 = a2 * kap; r2 = r2 * kap; }
+    am = fabs(a2); rm = fabs(r2);
+}
+__device__ __forceinline__ double quad_max(double x) {
+    return fmax(fmax(quad_bcast<0>(x), quad_bcast<1>(x)), fmax(quad_bcast<2>(x), quad_bcast<3>(x)));
+}
+
 // A workgroup is p.stream_waves wavefronts (1-4), each with its own tile and its own LDS column block; the workgroup shares
 // one LDS copy of the ziggurat's WI / KI tables for the direction draw (4 KB; D = 100 x 64 lanes: three 51 200 B column
 // blocks + the tables = 157.7 KB, one workgroup per CU).
@@ -776,20 +869,24 @@ template <int MODEL, bool OVERRELAX, int VARIANT, int W>
 __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail, const int do_head, const int draw_slot, const unsigned bid,
                                             const unsigned tid) {      // bid / tid: blockIdx.x / threadIdx.x (klhr_tile_kernel passes them through an optimisation barrier)
     extern __shared__ double lds[];            // [waves][D][W] column scratch (normals, then theta - mean), then the ziggurat tables
+    constexpr int QN = W == 16 ? 4 : 1;                          // 16-chain tiles: quad mode (four lanes per chain)
     const int lane = tid & 63, wv = tid >> 6;
+    const int cl = QN == 4 ? lane >> 2 : lane;                  // the lane's chain of the tile
+    const int q = QN == 4 ? lane & 3 : 0;                       // its phase: coordinates q, q + QN, ...
+    const bool own = q == 0;                                    // the quad's lane that stores the per-chain scalars
     const bool pair = p.stream_pair != 0;
     const int role = pair ? (wv & 1) : 2;                       // 0: the tile's tail, 1: the tile's head, 2: both (one wavefront per tile)
     const int tslot = pair ? wv >> 1 : wv;                      // the workgroup's tile this wavefront works on
     const int tiles_wg = pair ? p.stream_waves >> 1 : p.stream_waves;
     const long long tile = (long long)bid * tiles_wg + tslot;
-    const long long c = tile * W + lane;
+    const long long c = tile * W + cl;
     const int D = p.D, nc = p.ncol, K = p.J;
-    double *Z = lds + (size_t)tslot * (pair ? 2 : 1) * D * W + lane;       // tail: u = theta' - mean
+    double *Z = lds + (size_t)tslot * (pair ? 2 : 1) * D * W + cl;         // tail: u = theta' - mean
     double *Zn = pair ? Z + (size_t)D * W : Z;                              // head: the normals (pair mode: a column of its own)
     double *zwi = lds + (size_t)p.stream_waves * D * W;
     uint64_t *zki = reinterpret_cast<uint64_t *>(zwi + 256);
     // pair mode: per tile 4 x W words for the RNG hand-over, then one word per workgroup: a chain closes a window in this launch
-    unsigned long long *hand = reinterpret_cast<unsigned long long *>(zwi + 512) + (size_t)tslot * 4 * W + lane;
+    unsigned long long *hand = reinterpret_cast<unsigned long long *>(zwi + 512) + (size_t)tslot * 4 * W + cl;
     int *closing = reinterpret_cast<int *>(zwi + 512 + (size_t)tiles_wg * 4 * W);
     if ((do_head && (p.phases & PH_DIR)) || pair) {
         for (int i = tid; i < 256; i += blockDim.x) { zwi[i] = KLHR_ZIG_WI[i]; zki[i] = KLHR_ZIG_KI[i]; }
@@ -797,11 +894,11 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
         __syncthreads();
     }
     // (a wavefront whose tile lies beyond the last chain ends here; s_barrier waits for the surviving wavefronts only)
-    if (lane >= W || c >= p.C) return;
+    if (cl >= W || c >= p.C) return;
     const bool run_tail = do_tail != 0, run_head = do_head != 0;
-    const long long tb = tile * D * W + lane;
-    const long long tbe = tile * D * nc * W + lane;
-    const long long tbv = tile * D * K * W + lane;
+    const long long tb = tile * D * W + cl;
+    const long long tbe = tile * D * nc * W + cl;
+    const long long tbv = tile * D * K * W + cl;
     const bool diag = (p.flags & FLAG_DIAG) != 0;
     double *const theta = p.theta + tb, *const rho = p.d_rho + tb;
 #ifdef KLHR_STAMPS
@@ -825,7 +922,7 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
     bool closed = false, upd = false, closing_any = false;
     if (tail_here) {
         // grad_evals += nfev1 + 8 nfev2 of the fit that preceded this tail (klhr_sinh.py:188,200)
-        if (p.phases & PH_FIT) p.grad_evals[c] += (long long)KLHR_FB(p, F_NFEV1, c) + 8 * (long long)KLHR_FB(p, F_NFEV2, c);
+        if (own && (p.phases & PH_FIT)) p.grad_evals[c] += (long long)KLHR_FB(p, F_NFEV1, c) + 8 * (long long)KLHR_FB(p, F_NFEV2, c);
         if (mh) {
             const LineStat st = load_stat(p, c);
             nn = KLHR_FB(p, F_NN, c);
@@ -855,7 +952,7 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
             const int a = logu < mn ? 1 : 0;
             ad = (double)a; na = (double)(1 - a);
             acc += (ad - acc) / (double)draw;
-            if (diag) { double *dd = p.d_diag + c * KLHR_NDIAG; dd[KLHR_D_ZP] = zp; dd[KLHR_D_R] = r; dd[KLHR_D_LOGU] = logu; dd[KLHR_D_ACCEPT] = a; }
+            if (diag && own) { double *dd = p.d_diag + c * KLHR_NDIAG; dd[KLHR_D_ZP] = zp; dd[KLHR_D_R] = r; dd[KLHR_D_LOGU] = logu; dd[KLHR_D_ACCEPT] = a; }
         }
         KLHR_STAMP(st_mh);
         if (adapt && !(p.warmup < p.windowsize) && p.nclos > 0) {
@@ -885,38 +982,46 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
         bool fin = true;
         double *const om_m = p.om_m + tb, *const om_v = p.om_v + tb;
         const double *const mean = p.mean + tb;
-        for_chunks_pipelined<ST_CH, BufT1>(D,
-            [&](auto &b, int i0) {
+        for_chunks_pipelined<ST_CH, BufT1, QN>(D,
+            [&](auto &b, int s0, auto full) {
 #pragma unroll
                 for (int k = 0; k < b.n; k++) {
-                    b.th[k] = theta[(i0 + k) * W];
-                    b.rr[k] = mh ? rho[(i0 + k) * W] : 0.0;
-                    if (upd) { b.mm[k] = om_m[(i0 + k) * W]; b.vv[k] = om_v[(i0 + k) * W]; b.mn[k] = mean[(i0 + k) * W]; }
+                    const int i = (s0 + k) * QN + q;
+                    const int ic = full || i < D ? i : D - 1;
+                    b.th[k] = theta[ic * W];
+                    b.rr[k] = mh ? rho[ic * W] : 0.0;
+                    if (upd) { b.mm[k] = om_m[ic * W]; b.vv[k] = om_v[ic * W]; b.mn[k] = mean[ic * W]; }
                 }
             },
-            [&](auto &b, int i0) {
+            [&](auto &b, int s0, auto full) {
 #pragma unroll
                 for (int k = 0; k < b.n; k++) {
-                    const int i = i0 + k;
-                    double nx = b.th[k];
+                    const int i = (s0 + k) * QN + q;
+                    const bool valid = full || i < D;
+                    double nx = b.th[k], dd = 0.0;
                     if (mh) {
                         const double rho_i = b.rr[k] / nn;
                         const double thp = add_rn(mul_rn(zp, rho_i), b.th[k]);
                         nx = add_rn(mul_rn(ad, thp), mul_rn(na, b.th[k]));     // a*thetap + (1-a)*theta
-                        if (VARIANT == VAR_GAUSS) d2 += (nx - b.th[k]) * (nx - b.th[k]);
-                        theta[i * W] = nx;
+                        if (VARIANT == VAR_GAUSS) dd = (nx - b.th[k]) * (nx - b.th[k]);
+                        if (valid) theta[i * W] = nx;
                     }
-                    if (!isfinite(nx)) fin = false;
-                    if (out) out[i] = nx;
-                    if (i > 0 || MODEL != MODEL_FUNNEL) ssq += nx * nx;
+                    if (valid && !isfinite(nx)) fin = false;
+                    if (out && valid) out[i] = nx;
+                    if constexpr (VARIANT == VAR_GAUSS)
+                        seq_each<QN, decltype(full)::value>(s0 + k, D, [&](int ii, double sq, double dv) { if (mh) d2 += dv; if (ii > 0 || MODEL != MODEL_FUNNEL) ssq += sq; }, nx * nx, dd);
+                    else
+                        seq_each<QN, decltype(full)::value>(s0 + k, D, [&](int ii, double sq) { if (ii > 0 || MODEL != MODEL_FUNNEL) ssq += sq; }, nx * nx);
                     if (upd) {
                         double mi = b.mm[k], vi = b.vv[k];
                         const double d = nx - mi;
                         mi += d * w;
                         vi += -vi * w + d * d * w * (1 - w);
-                        om_m[i * W] = mi;
-                        om_v[i * W] = vi;
-                        Z[i * W] = nx - b.mn[k];
+                        if (valid) {
+                            om_m[i * W] = mi;
+                            om_v[i * W] = vi;
+                            Z[i * W] = nx - b.mn[k];
+                        }
                     }
                 }
             });
@@ -942,7 +1047,7 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
     for (int pass = 0; pass < 2; pass++) {
     if (pass == 0 && tail_here) {
         if (closed) {
-            split_close_window<W>(p, c, tb, tbe, tbv, omN, Z);
+            split_close_window<W>(p, c, tb, tbe, tbv, omN, Z, q);
             omN = 0;
             pcan = 0;
             if (VARIANT == VAR_GAUSS) {      // klhr.py:212-214
@@ -962,7 +1067,7 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
                     g0 = -v * (1.0 / 9.0) - 0.5 * (double)p.md.n + 0.5 * ev * ssq;
                 }
                 double *const omd_m = p.omd_m + tb, *const omd_v = p.omd_v + tb;
-                for_chunks<ST_CH>(D, [&](auto n, int i0) {
+                for_chunks<ST_CH, QN>(D, q, [&](auto n, int i0) {
                     constexpr int N = decltype(n)::value;
                     double th[N], mm[N], vv[N];
 #pragma unroll
@@ -981,7 +1086,7 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
                 });
             }
             pcan += 1;
-            split_pca_update<W>(p, p.pca_v + tbv, pcan, Z);
+            split_pca_update<W>(p, p.pca_v + tbv, pcan, Z, q);
         }
         KLHR_STAMP(st_pca);
     }
@@ -992,31 +1097,63 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
         LineStat st = {0, 0, 0, 0, 0, 0, 0};
         double Bs = 0, Cs = 0, m1 = 0;       // direction sums, still on the unnormalised r
         double prev_th = 0, prev_r = 0;      // (ar1: the previous coordinate)
+        double n2 = 0;
+        double m0l = 0, m1l = 0, nanl = 0;   // (quad mode: the lane's maxima)
+        // one coordinate of the line sums (and of the direction's norm): lane = chain in index order as it comes; quad mode
+        // element-wise on the lane's own coordinate, then the quad's four terms in index order
+        auto line_step = [&](auto full, auto with_n2, int step, int i, bool valid, double th, double r) {
+            if constexpr (QN == 1) {
+                if constexpr (decltype(with_n2)::value) n2 += (r + p.tol) * (r + p.tol);
+                line_accumulate<MODEL>(p, i, th, r, st, Bs, Cs, m1, prev_th, prev_r);
+            } else {
+                double pth = 0, pr = 0;
+                if constexpr (MODEL == MODEL_AR1) {
+                    pth = quad_prev(th); pr = quad_prev(r);
+                    if (q == 0) { pth = prev_th; pr = prev_r; }
+                    prev_th = quad_bcast<3>(th); prev_r = quad_bcast<3>(r);
+                }
+                double a, rs, am, rm;
+                line_elem<MODEL>(p, valid ? i : D - 1, th, r, pth, pr, a, rs, am, rm);
+                if (valid && !(MODEL == MODEL_FUNNEL && i == 0)) {
+                    m0l = fmax(m0l, am); m1l = fmax(m1l, rm);
+                    if (am != am || rm != rm) nanl = 1.0;
+                }
+                auto sums = [&](int ii, double ab, double rb) {
+                    if (MODEL == MODEL_FUNNEL && ii == 0) { st.v0 = ab; st.r0 = rb; }
+                    else { st.A = fma(ab, ab, st.A); Bs = fma(ab, rb, Bs); Cs = fma(rb, rb, Cs); }
+                };
+                if constexpr (decltype(with_n2)::value)
+                    seq_each<QN, decltype(full)::value>(step, D, [&](int ii, double ab, double rb, double nb) { n2 += nb; sums(ii, ab, rb); }, a, rs, (r + p.tol) * (r + p.tol));
+                else
+                    seq_each<QN, decltype(full)::value>(step, D, sums, a, rs);
+            }
+        };
         if (p.phases & PH_DIR) {
-            if (role == 2) draw_normals();
+            if (role == 2) { draw_normals(); if (QN > 1) KLHR_WAVE_SYNC(); }      // (the direction gathers normals written by the quad's other lanes)
             KLHR_STAMP(st_norm);
-            double n2 = 0;
             const int *const rank = p.rank + tb;
             if (p.dir_m != nullptr && !(p.flags & FLAG_EIGEN_ONE)) {
                 // the window-constant mean and sqrt(cov) come from the cache (written at the closure / by the state setters: the same
                 // operations in the same order): two rows to read instead of eigvecs' columns + cov, no sqrt and no weights per draw
                 const double *const dm = p.dir_m + tb, *const ds = p.dir_s + tb;
-                for_chunks_pipelined<ST_CH, BufDirC>(D,
-                    [&](auto &b, int i0) {
+                for_chunks_pipelined<ST_CH, BufDirC, QN>(D,
+                    [&](auto &b, int s0, auto full) {
 #pragma unroll
                         for (int k = 0; k < b.n; k++) {
-                            b.m[k] = dm[(i0 + k) * W]; b.s[k] = ds[(i0 + k) * W];
-                            b.rk[k] = rank[(i0 + k) * W]; b.th[k] = theta[(i0 + k) * W];
+                            const int i = (s0 + k) * QN + q;
+                            const int ic = full || i < D ? i : D - 1;
+                            b.m[k] = dm[ic * W]; b.s[k] = ds[ic * W];
+                            b.rk[k] = rank[ic * W]; b.th[k] = theta[ic * W];
                         }
                     },
-                    [&](auto &b, int i0) {
+                    [&](auto &b, int s0, auto full) {
 #pragma unroll
                         for (int k = 0; k < b.n; k++) {
-                            const int i = i0 + k;
+                            const int i = (s0 + k) * QN + q;
+                            const bool valid = full || i < D;
                             const double r = b.m[k] + b.s[k] * Zn[b.rk[k] * W];
-                            n2 += (r + p.tol) * (r + p.tol);
-                            rho[i * W] = r;
-                            line_accumulate<MODEL>(p, i, b.th[k], r, st, Bs, Cs, m1, prev_th, prev_r);
+                            if (valid) rho[i * W] = r;
+                            line_step(full, std::true_type(), s0 + k, i, valid, b.th[k], r);
                         }
                     });
             } else {
@@ -1044,46 +1181,62 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
             for (int j = 0; j < 4; j++) wj[j] = pick >= 0 ? (j == pick ? 1.0 : 0.0) : ((VARIANT == VAR_GAUSS || VARIANT == VAR_SLICE) ? (j < nc ? ev[j] : 0.0) : pj[j]);
             const double *const evec = p.eigvecs + tbe, *const cov = p.cov + tb;
             const long long es = (long long)nc * W;
-            for_chunks_pipelined<ST_CH, BufDir>(D,
-                [&](auto &b, int i0) {
+            for_chunks_pipelined<ST_CH, BufDir, QN>(D,
+                [&](auto &b, int s0, auto full) {
 #pragma unroll
                     for (int k = 0; k < b.n; k++) {
-                        b.e0[k] = evec[(i0 + k) * es];
-                        b.e1[k] = nc > 1 ? evec[(i0 + k) * es + W] : 0.0;
-                        b.e2[k] = nc > 2 ? evec[(i0 + k) * es + 2 * W] : 0.0;
-                        b.cv[k] = cov[(i0 + k) * W]; b.rk[k] = rank[(i0 + k) * W]; b.th[k] = theta[(i0 + k) * W];
+                        const int i = (s0 + k) * QN + q;
+                        const int ic = full || i < D ? i : D - 1;
+                        b.e0[k] = evec[ic * es];
+                        b.e1[k] = nc > 1 ? evec[ic * es + W] : 0.0;
+                        b.e2[k] = nc > 2 ? evec[ic * es + 2 * W] : 0.0;
+                        b.cv[k] = cov[ic * W]; b.rk[k] = rank[ic * W]; b.th[k] = theta[ic * W];
                     }
                 },
-                [&](auto &b, int i0) {
+                [&](auto &b, int s0, auto full) {
 #pragma unroll
                     for (int k = 0; k < b.n; k++) {
-                        const int i = i0 + k;
+                        const int i = (s0 + k) * QN + q;
+                        const bool valid = full || i < D;
+                        const int ic = valid ? i : D - 1;
                         double m = 0;
-                        if (pick >= 0) m = pick == 0 ? b.e0[k] : (pick == 1 ? b.e1[k] : (pick == 2 ? b.e2[k] : evec[i * es + 3 * W]));
+                        if (pick >= 0) m = pick == 0 ? b.e0[k] : (pick == 1 ? b.e1[k] : (pick == 2 ? b.e2[k] : evec[ic * es + 3 * W]));
                         else {
                             m += wj[0] * b.e0[k];
                             if (nc > 1) m += wj[1] * b.e1[k];
                             if (nc > 2) m += wj[2] * b.e2[k];
-                            if (nc > 3) m += wj[3] * evec[i * es + 3 * W];
+                            if (nc > 3) m += wj[3] * evec[ic * es + 3 * W];
                         }
                         const double r = m + sqrt(b.cv[k]) * Zn[b.rk[k] * W];
-                        n2 += (r + p.tol) * (r + p.tol);
-                        rho[i * W] = r;
-                        line_accumulate<MODEL>(p, i, b.th[k], r, st, Bs, Cs, m1, prev_th, prev_r);
+                        if (valid) rho[i * W] = r;
+                        line_step(full, std::true_type(), s0 + k, i, valid, b.th[k], r);
                     }
                 });
             }
             nn = sqrt(n2);
         } else {
             // direction given in d_rho (klhr_fit / klhr_metropolis / probes of the C ABI): nn = 1
-            for_chunks<ST_CH>(D, [&](auto n, int i0) {
-                constexpr int N = decltype(n)::value;
-                double rr[N], th[N];
+            if constexpr (QN == 1) {
+                for_chunks<ST_CH>(D, 0, [&](auto n, int i0) {
+                    constexpr int N = decltype(n)::value;
+                    double rr[N], th[N];
 #pragma unroll
-                for (int k = 0; k < N; k++) { rr[k] = rho[(i0 + k) * W]; th[k] = theta[(i0 + k) * W]; }
+                    for (int k = 0; k < N; k++) { rr[k] = rho[(i0 + k) * W]; th[k] = theta[(i0 + k) * W]; }
 #pragma unroll
-                for (int k = 0; k < N; k++) line_accumulate<MODEL>(p, i0 + k, th[k], rr[k], st, Bs, Cs, m1, prev_th, prev_r);
-            });
+                    for (int k = 0; k < N; k++) line_accumulate<MODEL>(p, i0 + k, th[k], rr[k], st, Bs, Cs, m1, prev_th, prev_r);
+                });
+            } else {
+                for (int s0 = 0; s0 * QN < D; s0++) {
+                    const int i = s0 * QN + q;
+                    const bool valid = i < D;
+                    const int ic = valid ? i : D - 1;
+                    line_step(std::false_type(), std::false_type(), s0, i, valid, theta[ic * W], rho[ic * W]);
+                }
+            }
+        }
+        if constexpr (QN > 1) {
+            st.m0 = quad_max(nanl) > 0.0 ? NAN : quad_max(m0l);
+            m1 = quad_max(m1l);
         }
         {
             const double inv = 1.0 / nn;
@@ -1092,15 +1245,17 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
         }
         if (diag && (p.phases & PH_DIR)) {
             // diagnostics / klhr_random_direction: leave the normalised direction itself in d_rho (nn becomes 1)
-            for (int i = 0; i < D; i++) rho[i * W] = rho[i * W] / nn;
+            for (int i = q; i < D; i += QN) rho[i * W] = rho[i * W] / nn;
             nn = 1.0;
         }
+        if (own) {
         KLHR_FB(p, F_S0, c) = st.v0; KLHR_FB(p, F_S1, c) = st.r0; KLHR_FB(p, F_S2, c) = st.A; KLHR_FB(p, F_S3, c) = st.B;
         KLHR_FB(p, F_S4, c) = st.C; KLHR_FB(p, F_S5, c) = st.m0; KLHR_FB(p, F_S6, c) = st.m1; KLHR_FB(p, F_NN, c) = nn;
+        }
         if (p.phases & PH_FIT) {
             // fit() consumes five normals — x0, then size-4 init of which the first two are overwritten (klhr_sinh.py:184,
             // 191-193); klhr.py's fit draws only x0 (klhr.py:134-139); SUBKLHRSINH draws size 3 (sub_klhr_sinh.py:184)
-            KLHR_FB(p, F_X0, c) = rng_std_normal_call(rng) * p.initscale;
+            const double x0v = rng_std_normal_call(rng) * p.initscale;
             double n2v = 0, n3v = 0;
             if (VARIANT != VAR_GAUSS) {
                 (void)rng_std_normal_call(rng);
@@ -1108,7 +1263,7 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
                 n2v = rng_std_normal_call(rng) * p.initscale;
                 if (VARIANT == VAR_SINH) n3v = rng_std_normal_call(rng) * p.initscale;
             }
-            KLHR_FB(p, F_N2, c) = n2v; KLHR_FB(p, F_N3, c) = n3v;
+            if (own) { KLHR_FB(p, F_X0, c) = x0v; KLHR_FB(p, F_N2, c) = n2v; KLHR_FB(p, F_N3, c) = n3v; }
         }
         KLHR_STAMP(st_dir);
     }
@@ -1116,8 +1271,8 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
     }
 
     // ---- store the per-chain scalars (pair mode: the RNG state by the head's wavefront, the rest by the tail's)
-    if (role != 0) { p.rng[c * 4 + 0] = rng.sh; p.rng[c * 4 + 1] = rng.sl; p.rng[c * 4 + 2] = rng.ih; p.rng[c * 4 + 3] = rng.il; }
-    if (role != 1) {
+    if (role != 0 && own) { p.rng[c * 4 + 0] = rng.sh; p.rng[c * 4 + 1] = rng.sl; p.rng[c * 4 + 2] = rng.ih; p.rng[c * 4 + 3] = rng.il; }
+    if (role != 1 && own) {
         p.counters[c * 4 + 0] = draw; p.counters[c * 4 + 1] = omN; p.counters[c * 4 + 2] = pcan; p.counters[c * 4 + 3] = cidx;
         p.acc[c] = acc;
         if (VARIANT == VAR_GAUSS) { p.kstate[c * 4 + 0] = sm_x; p.kstate[c * 4 + 1] = sm_cnt; p.kstate[c * 4 + 2] = (double)Kc; p.kstate[c * 4 + 3] = moved_f; }
