@@ -415,9 +415,11 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
         if (const char *e = getenv("KLHR_FITN")) s->fitn = atoi(e) != 0;
         // few chains: klhr_step runs whole iterations per 16-chain tile in ONE launch (klhr_tile_kernel: the pair-mode streaming
         // body and the node-parallel fit body in a loop over the draws, one workgroup per tile).  Needs what those two need.
-        // One wavefront per SIMD by register count: up to 8 192 chains (1 024 wavefronts); measured in klhr_split.hpp.
+        // Up to 16 384 chains (2 048 wavefronts: two per SIMD, the kernel's 256-register build); measured in klhr_split.hpp.
         const bool fused_ok = s->tw == 16 && s->fitn && ((size_t)2 * D * 16 + 512 + 65) * 8 <= 160 * 1024;
-        s->fused = fused_ok && s->C <= 8192;
+        long long fused_max = 16384;
+        if (const char *e = getenv("KLHR_FUSED_MAX")) fused_max = atoll(e);                  // (tuning aid)
+        s->fused = fused_ok && s->C <= fused_max;
         if (const char *e = getenv("KLHR_FUSED")) s->fused = s->fused && atoi(e) != 0;      // (0: the kernel sequence; used by the parity tests)
         // Chain groups of klhr_step: the streaming kernel is bound by memory, the fit kernels by the fp64 ALUs; with the chains
         // in two groups on two HIP streams one group's fit overlaps the other group's streaming.  (Tuning aid: KLHR_GROUPS.)

@@ -33,13 +33,15 @@ static void launch_split_model(const KParams &kp0, int what, bool overrelaxed, i
         // whole iterations per tile (klhr_tile_kernel): one workgroup of two wavefronts per 16-chain tile, kp.n_iters draws
         kp.stream_pair = 1; kp.stream_waves = 2;
         const size_t lds = ((size_t)2 * kp.D * 16 + KLHR_ZTAB_DOUBLES + 4 * 16 + 1) * sizeof(double);
-        if (overrelaxed) {
-            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)klhr_tile_kernel<MODEL, true, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((klhr_tile_kernel<MODEL, true, V>), dim3(stiles), dim3(128), lds, stream, kp);
-        } else {
-            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)klhr_tile_kernel<MODEL, false, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((klhr_tile_kernel<MODEL, false, V>), dim3(stiles), dim3(128), lds, stream, kp);
-        }
+        // up to 8 192 chains one wavefront per SIMD holds every tile; beyond, the 256-register build (two per SIMD)
+#define KLHR_LAUNCH_TILE(O, WV)                                                                                                        \
+    do {                                                                                                                               \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)klhr_tile_kernel<MODEL, O, V, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((klhr_tile_kernel<MODEL, O, V, WV>), dim3(stiles), dim3(128), lds, stream, kp);                              \
+    } while (0)
+        if (stiles <= 512) { if (overrelaxed) KLHR_LAUNCH_TILE(true, 1); else KLHR_LAUNCH_TILE(false, 1); }
+        else { if (overrelaxed) KLHR_LAUNCH_TILE(true, 2); else KLHR_LAUNCH_TILE(false, 2); }
+#undef KLHR_LAUNCH_TILE
     } else if (what == 4) {
         hipLaunchKernelGGL((klhr_fitn_kernel<MODEL, V>), dim3((unsigned)((kp.C + 7) / 8)), block, 0, stream, kp);
     } else if (what == 3) {

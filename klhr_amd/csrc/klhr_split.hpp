@@ -571,13 +571,11 @@ __device__ __forceinline__ void for_chunks(int D, int q, F f) {
 #ifndef KLHR_ST_CH1
 #define KLHR_ST_CH1 16
 #endif
-#ifndef KLHR_ST_QDIV
-#define KLHR_ST_QDIV 4
-#endif
-// (inside functions templated on the tile width W.  16-chain tiles: half the chunk — measured the same speed, and the
-//  streaming kernel then fits 256 registers, i.e. two wavefronts per SIMD, which its pair mode needs)
-#define ST_CH (W == 16 ? KLHR_ST_CH / KLHR_ST_QDIV : KLHR_ST_CH)          // passes over several arrays
-#define ST_CH1 (W == 16 ? KLHR_ST_CH1 / KLHR_ST_QDIV : KLHR_ST_CH1)       // passes over one or two arrays
+// (inside functions templated on the tile width W and on CHDIV.  16-chain tiles, quad mode: a step is four coordinates and the chunk
+//  KLHR_ST_CH / CHDIV steps — CHDIV = 4: 250 registers, two wavefronts per SIMD for the streaming kernel's pair mode; CHDIV = 8:
+//  170 registers, which lets klhr_tile_kernel — this body plus the fit's — run two wavefronts per SIMD)
+#define ST_CH (W == 16 ? KLHR_ST_CH / CHDIV : KLHR_ST_CH)          // passes over several arrays
+#define ST_CH1 (W == 16 ? KLHR_ST_CH1 / CHDIV : KLHR_ST_CH1)       // passes over one or two arrays
 
 // Software-pipelined form: `load(buf, s0, full)` fills a register buffer with the chunk of CH steps at s0, `compute(buf, s0,
 // full)` consumes it.  The loads of chunk j+1 are issued before chunk j is computed (two buffers): a wavefront of this kernel
@@ -647,7 +645,7 @@ template <int N> struct BufDirC { static constexpr int n = N; double m[N], s[N],
 // onlinepca.py:13-26 for the chain of this lane (quad).  u = theta - mean in Z (LDS column of the chain, stride W), V = the tile's
 // pca_v rows.  Per component: sums (s, u.v) -> v' = w v + (1-w) u (u.v)/(|v|+tol), sums on v' -> u -= (u.v') v'/(|v'|^2+tol);
 // the deflation pass of component j also gathers the first sums of component j+1.  q: the lane's phase in quad mode (0 otherwise).
-template <int W>
+template <int W, int CHDIV>
 __device__ inline void split_pca_update(const KParams &p, double *V, long long n_new, double *Z, const int q) {
     constexpr int QN = W == 16 ? 4 : 1;
     const int D = p.D, K = p.J;
@@ -865,7 +863,7 @@ __device__ __forceinline__ double quad_max(double x) {
 //   b1 after the MH scalars (A hands the RNG state over in LDS), b2 after T1 (theta' is in HBM), b3 after the tail —
 // B's direction pass goes before b3 unless a chain of the workgroup closes a window.  Every chain's arithmetic is the
 // single-wavefront form's, operation for operation.
-template <int MODEL, bool OVERRELAX, int VARIANT, int W>
+template <int MODEL, bool OVERRELAX, int VARIANT, int W, int CHDIV = 4>
 __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail, const int do_head, const int draw_slot, const unsigned bid,
                                             const unsigned tid) {      // bid / tid: blockIdx.x / threadIdx.x (klhr_tile_kernel passes them through an optimisation barrier)
     extern __shared__ double lds[];            // [waves][D][W] column scratch (normals, then theta - mean), then the ziggurat tables
@@ -1086,7 +1084,7 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
                 });
             }
             pcan += 1;
-            split_pca_update<W>(p, p.pca_v + tbv, pcan, Z, q);
+            split_pca_update<W, CHDIV>(p, p.pca_v + tbv, pcan, Z, q);
         }
         KLHR_STAMP(st_pca);
     }
@@ -1296,19 +1294,16 @@ template <int MODEL, bool OVERRELAX, int VARIANT>
 __global__ __launch_bounds__(256, 2) void klhr_stream16_kernel(const KParams p, const int do_tail, const int do_head) {
     stream_body<MODEL, OVERRELAX, VARIANT, 16>(p, do_tail, do_head, p.draw_slot, blockIdx.x, threadIdx.x);
 }
-// Few chains (up to 8 192): WHOLE ITERATIONS of a tile in one workgroup, all the draws of a call in one launch.  A tile of 16
-// chains is two wavefronts in the streaming part (pair mode: tail | head) and two wavefronts in the fit (8 lanes per chain, 8
-// chains per wavefront), and nothing of an iteration crosses tiles — so the workgroup loops over the iterations on its own:
-// no launch boundaries, no wait for the slowest chain of the whole launch (a tile waits for the slowest of its 16), and tiles
-// drift apart, so that some stream (memory) while others fit (ALU).  Streaming and fit code are the kernels' own bodies.
-// One wavefront per SIMD (336 registers, no scratch; built for two it spills 90 registers and is slower than the kernel
-// sequence): 8 192 chains = 512 tiles = 1 024 wavefronts fill the machine once.  ill-normal-100, us per iteration, kernel
-// sequence | this kernel: 2 048 chains 137 | 110, 4 096: 145 | 109, 8 192: 154 | 111 (16 384: 160 | 221, a second round).
-template <int MODEL, bool OVERRELAX, int VARIANT>
-#ifndef KLHR_TILE_WAVES
-#define KLHR_TILE_WAVES 1
-#endif
-__global__ __launch_bounds__(128, KLHR_TILE_WAVES) void klhr_tile_kernel(const KParams p) {
+// Few chains (up to 16 384): WHOLE ITERATIONS of a tile in one workgroup, all the draws of a call in one launch.  A tile of 16
+// chains is two wavefronts in the streaming part (pair mode: tail | head, each in quad mode) and two wavefronts in the fit (8
+// lanes per chain, 8 chains per wavefront), and nothing of an iteration crosses tiles — so the workgroup loops over the
+// iterations on its own: no launch boundaries, no wait for the slowest chain of the whole launch (a tile waits for the slowest
+// of its 16), and tiles drift apart, so that some stream (memory) while others fit (ALU).  Streaming and fit code are the
+// kernels' own bodies.  Two builds: WAVES = 1 wavefront per SIMD (308 registers, up to 8 192 chains = 512 tiles = 1 024
+// wavefronts) and WAVES = 2 (256 registers: the streaming body with half the chunk, 64-220 bytes of scratch; 8 193-16 384 chains).
+// ill-normal-100, us per iteration, kernel sequence | this kernel: 2 048 chains 137 | 88, 8 192: 154 | 94, 16 384: 139 | 121.
+template <int MODEL, bool OVERRELAX, int VARIANT, int WAVES>
+__global__ __launch_bounds__(128, WAVES) void klhr_tile_kernel(const KParams p) {
 #pragma unroll 1
     for (int it = 0; it <= p.n_iters; it++) {
         // (the indices go through an empty asm per iteration: everything derived from them — a dozen row addresses, the node
@@ -1316,7 +1311,7 @@ __global__ __launch_bounds__(128, KLHR_TILE_WAVES) void klhr_tile_kernel(const K
         unsigned bid = blockIdx.x, tid = threadIdx.x;
         asm volatile("" : "+s"(bid));
         asm volatile("" : "+v"(tid));
-        stream_body<MODEL, OVERRELAX, VARIANT, 16>(p, it > 0, it < p.n_iters, it - 1, bid, tid);
+        stream_body<MODEL, OVERRELAX, VARIANT, 16, WAVES == 2 ? 8 : 4>(p, it > 0, it < p.n_iters, it - 1, bid, tid);
         __syncthreads();                 // line sums, norm and the fit's normals of every chain of the tile are in HBM
         asm volatile("" : "+s"(bid));
         asm volatile("" : "+v"(tid));

@@ -83,14 +83,15 @@ def test_odd_chain_counts_every_variant(name):
 
 @pytest.mark.parametrize("name", ["funnel100", "ar1x100"])
 def test_mapping_thresholds_do_not_show_in_a_chain(name):
-    """The split pipeline switches mappings with the chain count: 16-chain tiles with paired streaming wavefronts up to 16 384
-    chains, 64-chain tiles above; the node-parallel fit kernel up to 32 768 chains, the lane = chain fit kernels above.
+    """The split pipeline switches mappings with the chain count: whole iterations per 16-chain tile (quad mode: four lanes per
+    chain) in one launch up to 16 384 chains — the one-wavefront-per-SIMD build up to 8 192, the two-per-SIMD build above —,
+    64-chain tiles (lane = chain) above; the node-parallel fit kernel up to 32 768 chains, the lane = chain fit kernels above.
     The first chains' states after 60 draws (first window closure included) are the same bits on both sides of each threshold
     and in a small launch."""
     stem, data = model_spec(name)
     n, base = 60, 31000
     ref = None
-    for C in (40, 16384, 16385, 32768, 32769):
+    for C in (40, 8192, 8193, 16384, 16385, 32768, 32769):
         s = make_sampler(stem, data, C, warmup=100)
         s.seed(np.arange(C, dtype=np.uint64) + base)
         s.step(n)
