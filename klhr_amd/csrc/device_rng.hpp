@@ -170,6 +170,99 @@ __device__ inline void rng_std_normal_column(Pcg64 &g, double *dst, int stride, 
     }
 }
 
+// D standard normals of ONE chain drawn by the four lanes of its DPP quad (quad mode of the streaming kernel: lane = 4 * chain +
+// q), into dst[k * stride].  PCG64 is a 128-bit LCG: lane q holds the state q + 1 steps ahead of the chain's and advances four
+// steps at a time (state * M^4 + inc * (1 + M + M^2 + M^3)), so one round yields the chain's next four raw outputs and — when all
+// four pass the ziggurat's fast test, 95 % of the rounds — its next four normals.  When lane f fails, the lanes below it keep
+// their normals, the quad takes lane f's state and draw, PARKS (as in rng_std_normal_column) and finishes that normal with
+// rng_std_normal_slow — consuming however many further outputs that takes, sequentially — before the four lanes fan out again
+// from the state it leaves.  Same values in the same order as Generator.standard_normal() D times, and the generator ends at
+// the same position.  g: the chain's generator, identical in the quad's four lanes on entry and on return.
+#ifndef KLHR_ZIGQ_BATCH
+#define KLHR_ZIGQ_BATCH 4
+#endif
+__device__ __forceinline__ uint64_t quad_lane_u64(uint64_t v, int src_lane) {
+    const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(uint32_t)v);
+    const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(uint32_t)(v >> 32));
+    return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+__device__ inline void rng_std_normal_quad(Pcg64 &g, double *dst, int stride, int D, int lane, const double *wi_l, const uint64_t *ki_l) {
+    const u128 M1 = (((u128)0x2360ED051FC65DA4ULL) << 64) | (u128)0x4385DF649FCCF645ULL, G1 = 1;
+    const u128 M2 = (((u128)0x17BCE35BDF69743CULL) << 64) | (u128)0x529ED9EB20E0AE99ULL, G2 = (((u128)0x2360ED051FC65DA4ULL) << 64) | (u128)0x4385DF649FCCF646ULL;
+    const u128 M3 = (((u128)0x25F041404BD80E82ULL) << 64) | (u128)0xEB5AE837ED42153DULL, G3 = (((u128)0x3B1DD060FF2FD1E0ULL) << 64) | (u128)0x9624B94FC0ADA4DFULL;
+    const u128 M4 = (((u128)0xF4DD417327DB7A9BULL) << 64) | (u128)0xD194DFBE42D45771ULL, G4 = (((u128)0x610E11A14B07E063ULL) << 64) | (u128)0x817FA187ADEFBA1CULL;
+    const int q = lane & 3, qbase = lane & ~3;
+    const u128 inc = (((u128)g.ih) << 64) | g.il;
+    const u128 inc_g4 = inc * G4;
+    const u128 Mq = q == 0 ? M1 : (q == 1 ? M2 : (q == 2 ? M3 : M4));
+    const u128 inc_gq = inc * (q == 0 ? G1 : (q == 1 ? G2 : (q == 2 ? G3 : G4)));
+    uint64_t bh = g.sh, bl = g.sl;          // the chain's state (all four lanes)
+    uint64_t th, tl;                        // the lane's state: q + 1 steps past (bh, bl); parked: the failed draw's state (all four lanes)
+    { const u128 t = ((((u128)bh) << 64) | bl) * Mq + inc_gq; th = (uint64_t)(t >> 64); tl = (uint64_t)t; }
+    int k = 0, trip = 0, idx = 0;
+    uint64_t rabs = 0;
+    double x = 0.0;
+    bool parked = false;
+    for (;;) {
+        if (k < D && !parked) {
+            const uint64_t xo = th ^ tl;
+            const unsigned rot = (unsigned)(th >> 58);
+            uint64_t r = (xo >> rot) | (xo << ((-rot) & 63));
+            idx = (int)(r & 0xff);
+            const double wv = wi_l[idx];
+            const uint64_t kv = ki_l[idx];
+            // the stride-4 successor, computed while the two table reads are in flight (used unless a lane of the quad fails)
+            uint64_t nh, nl;
+            { const u128 t = ((((u128)th) << 64) | tl) * M4 + inc_g4; nh = (uint64_t)(t >> 64); nl = (uint64_t)t; }
+            asm volatile("" : "+v"(nh), "+v"(nl));
+            r >>= 8;
+            const int sign = (int)(r & 1);
+            rabs = (r >> 1) & 0x000fffffffffffffULL;
+            x = (double)rabs * wv;
+            if (sign) x = -x;
+            const int rem = D - k;
+            const bool fail = q < rem && !(rabs < kv);
+            const unsigned fm = (unsigned)(__ballot(fail) >> qbase) & 0xfu;          // the quad's lanes whose draw needs the slow branch
+            const int f = fm ? __ffs((int)fm) - 1 : 4;
+            if (q < f && q < rem) dst[(long long)(k + q) * stride] = x;
+            if (fm == 0 && rem > 4) {
+                k += 4;
+                th = nh; tl = nl;
+            } else {
+                // lane f's draw goes to the slow branch — or, with no failure, the column ends in this round with lane rem - 1's state
+                const int src = qbase + (fm ? f : rem - 1);
+                th = quad_lane_u64(th, src); tl = quad_lane_u64(tl, src);
+                if (fm) {
+                    k += f;
+                    idx = __builtin_amdgcn_ds_bpermute(src << 2, idx);
+                    rabs = quad_lane_u64(rabs, src);
+                    x = __longlong_as_double((long long)quad_lane_u64((uint64_t)__double_as_longlong(x), src));
+                    parked = true;
+                } else {
+                    k = D; bh = th; bl = tl;
+                }
+            }
+        }
+        ++trip;
+        const bool any_parked = __any(parked);
+        const bool all_stuck = !__any(k < D && !parked);
+        if (any_parked && (all_stuck || trip % KLHR_ZIGQ_BATCH == 0)) {
+            if (parked) {
+                Pcg64 t; t.sh = th; t.sl = tl; t.ih = g.ih; t.il = g.il;
+                const NormOut o = rng_std_normal_slow(t, idx, rabs, x);
+                dst[(long long)k * stride] = o.z;
+                k++;
+                bh = o.g.sh; bl = o.g.sl;
+                const u128 u = ((((u128)bh) << 64) | bl) * Mq + inc_gq;
+                th = (uint64_t)(u >> 64); tl = (uint64_t)u;
+                parked = false;
+            }
+        }
+        if (!__any(k < D)) break;
+    }
+    g.sh = bh; g.sl = bl;
+}
+
 // Generator.uniform() == 0.0 + (1.0 - 0.0) * next_double
 __device__ __forceinline__ double rng_uniform(Pcg64 &g) { return pcg_next_double(g); }
 

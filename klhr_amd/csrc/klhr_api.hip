@@ -416,7 +416,7 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
         // few chains: klhr_step runs whole iterations per 16-chain tile in ONE launch (klhr_tile_kernel: the pair-mode streaming
         // body and the node-parallel fit body in a loop over the draws, one workgroup per tile).  Needs what those two need.
         // Up to 16 384 chains (2 048 wavefronts: two per SIMD, the kernel's 256-register build); measured in klhr_split.hpp.
-        const bool fused_ok = s->tw == 16 && s->fitn && ((size_t)2 * D * 16 + 512 + 65) * 8 <= 160 * 1024;
+        const bool fused_ok = s->tw == 16 && s->fitn && ((size_t)2 * D * 16 + 512 + 66) * 8 <= 160 * 1024;
         long long fused_max = 16384;
         if (const char *e = getenv("KLHR_FUSED_MAX")) fused_max = atoll(e);                  // (tuning aid)
         s->fused = fused_ok && s->C <= fused_max;

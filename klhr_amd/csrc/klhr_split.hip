@@ -32,7 +32,7 @@ static void launch_split_model(const KParams &kp0, int what, bool overrelaxed, i
     } else if (what == 7) {
         // whole iterations per tile (klhr_tile_kernel): one workgroup of two wavefronts per 16-chain tile, kp.n_iters draws
         kp.stream_pair = 1; kp.stream_waves = 2;
-        const size_t lds = ((size_t)2 * kp.D * 16 + KLHR_ZTAB_DOUBLES + 4 * 16 + 1) * sizeof(double);
+        const size_t lds = ((size_t)2 * kp.D * 16 + KLHR_ZTAB_DOUBLES + 4 * 16 + 2) * sizeof(double);
         // up to 8 192 chains one wavefront per SIMD holds every tile; beyond, the 256-register build (two per SIMD)
 #define KLHR_LAUNCH_TILE(O, WV)                                                                                                        \
     do {                                                                                                                               \
@@ -47,7 +47,7 @@ static void launch_split_model(const KParams &kp0, int what, bool overrelaxed, i
     } else if (what == 3) {
         hipLaunchKernelGGL((klhr_probe_kernel<MODEL, V>), dim3(tiles), block, 0, stream, kp);
     } else {
-        const size_t lds = ((size_t)kp.stream_waves * kp.D * kp.tw + KLHR_ZTAB_DOUBLES + (kp.stream_pair ? (size_t)tiles_wg * 4 * kp.tw + 1 : 0)) * sizeof(double);
+        const size_t lds = ((size_t)kp.stream_waves * kp.D * kp.tw + KLHR_ZTAB_DOUBLES + (kp.stream_pair ? (size_t)tiles_wg * 4 * kp.tw + 2 : 0)) * sizeof(double);
 #define KLHR_LAUNCH_STREAM(KERNEL, O)                                                                                                  \
     do {                                                                                                                               \
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)KERNEL<MODEL, O, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \

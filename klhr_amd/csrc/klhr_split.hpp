@@ -571,6 +571,9 @@ __device__ __forceinline__ void for_chunks(int D, int q, F f) {
 #ifndef KLHR_ST_CH1
 #define KLHR_ST_CH1 16
 #endif
+#ifndef KLHR_RING_STEPS
+#define KLHR_RING_STEPS 2
+#endif
 // (inside functions templated on the tile width W and on CHDIV.  16-chain tiles, quad mode: a step is four coordinates and the chunk
 //  KLHR_ST_CH / CHDIV steps — CHDIV = 4: 250 registers, two wavefronts per SIMD for the streaming kernel's pair mode; CHDIV = 8:
 //  170 registers, which lets klhr_tile_kernel — this body plus the fit's — run two wavefronts per SIMD)
@@ -586,18 +589,36 @@ template <int CH, template <int> class BUF, int QN, class L, class C>
 __device__ __forceinline__ void for_chunks_pipelined(int D, L load, C compute) {
     const int NS = D / QN;
     const std::true_type full;
-    BUF<CH> a, b;
-    int s0 = 0;
-    if (CH <= NS) load(a, 0, full);
-    for (; s0 + 2 * CH <= NS; s0 += 2 * CH) {
-        load(b, s0 + CH, full);
-        compute(a, s0, full);
-        if (s0 + 3 * CH <= NS) load(a, s0 + 2 * CH, full);
-        compute(b, s0 + CH, full);
+    if constexpr (QN == 1) {
+        BUF<CH> a, b;
+        int s0 = 0;
+        if (CH <= NS) load(a, 0, full);
+        for (; s0 + 2 * CH <= NS; s0 += 2 * CH) {
+            load(b, s0 + CH, full);
+            compute(a, s0, full);
+            if (s0 + 3 * CH <= NS) load(a, s0 + 2 * CH, full);
+            compute(b, s0 + CH, full);
+        }
+        if (s0 + CH <= NS) { compute(a, s0, full); s0 += CH; }
+        for (; s0 < NS; ++s0) { BUF<1> r; load(r, s0, full); compute(r, s0, full); }
+    } else {
+        // quad mode: a step is a handful of values per lane — a ring of NB one-step buffers keeps NB steps' loads in flight
+        constexpr int NB = KLHR_RING_STEPS * CH;
+        BUF<1> r[NB];
+#pragma unroll
+        for (int j = 0; j < NB; j++) if (j < NS) load(r[j], j, full);
+        int s0 = 0;
+        for (; s0 + NB <= NS; s0 += NB) {
+#pragma unroll
+            for (int j = 0; j < NB; j++) {
+                compute(r[j], s0 + j, full);
+                if (s0 + j + NB < NS) load(r[j], s0 + j + NB, full);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; j++) if (s0 + j < NS) compute(r[j], s0 + j, full);
+        if (NS * QN < D) { BUF<1> t; load(t, NS, std::false_type()); compute(t, NS, std::false_type()); }
     }
-    if (s0 + CH <= NS) { compute(a, s0, full); s0 += CH; }
-    for (; s0 < NS; ++s0) { BUF<1> r; load(r, s0, full); compute(r, s0, full); }
-    if (QN > 1 && NS * QN < D) { BUF<1> r; load(r, NS, std::false_type()); compute(r, NS, std::false_type()); }
 }
 
 // ---- QUAD MODE (16-chain tiles): lane = (chain cl = lane >> 2, phase q = lane & 3) — the four lanes of a DPP quad walk one
@@ -610,15 +631,15 @@ __device__ __forceinline__ void for_chunks_pipelined(int D, L load, C compute) {
 template <int Q>
 __device__ __forceinline__ double quad_bcast(double x) {
     int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(0, lo, Q * 0x55, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, Q * 0x55, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_mov_dpp(lo, Q * 0x55, 0xf, 0xf, true);          // (every lane of a quad is active or none is)
+    hi = __builtin_amdgcn_mov_dpp(hi, Q * 0x55, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 // lane q <- lane q - 1 of the quad (lane 0 keeps its own value: the caller substitutes the previous step's last element)
 __device__ __forceinline__ double quad_prev(double x) {
     int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x90, 0xf, 0xf, false);      // quad_perm:[0,0,1,2]
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x90, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0x90, 0xf, 0xf, true);      // quad_perm:[0,0,1,2]
+    hi = __builtin_amdgcn_mov_dpp(hi, 0x90, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 // f(i, v...) for the elements of one step in index order: lane = chain calls it once with the lane's own values; quad mode four
@@ -637,8 +658,8 @@ __device__ __forceinline__ void seq_each(int step, int D, F f, T... v) {
 template <int N> struct Buf1 { static constexpr int n = N; double v[N]; };
 template <int N> struct Buf2 { static constexpr int n = N; double v[N], q[N]; };
 template <int N> struct BufT1 { static constexpr int n = N; double th[N], rr[N], mm[N], vv[N], mn[N]; };
-template <int N> struct BufDir { static constexpr int n = N; double e0[N], e1[N], e2[N], cv[N], th[N]; int rk[N]; };
-template <int N> struct BufDirC { static constexpr int n = N; double m[N], s[N], th[N]; int rk[N]; };
+template <int N> struct BufDir { static constexpr int n = N; double e0[N], e1[N], e2[N], cv[N], th[N], is[N]; int rk[N]; };
+template <int N> struct BufDirC { static constexpr int n = N; double m[N], s[N], th[N], is[N]; int rk[N]; };
 
 #pragma clang fp contract(off)      // NumPy's element-wise roundings and summation orders (bit-exact pieces)
 
@@ -832,13 +853,12 @@ __device__ __forceinline__ void line_accumulate(const KParams &p, int i, double 
 
 // Quad mode: the element-wise half of line_accumulate for the lane's own coordinate i (pth, pr: coordinate i - 1, ar1 only) —
 // a, rs enter the three fma chains in index order (seq_each), am, rm the maxima (order-free: a per-lane maximum, reduced over
-// the quad after the pass; a NaN coordinate makes m0 NaN)
+// the quad after the pass; a NaN coordinate makes m0 NaN).  is: ill-normal's 1 / s_i (the lanes of a quad need four different
+// ones: a vector load, fetched with the chunk's other loads)
 template <int MODEL>
-__device__ __forceinline__ void line_elem(const KParams &p, int i, double th, double r, double pth, double pr, double &a, double &rs, double &am,
-                                          double &rm) {
+__device__ __forceinline__ void line_elem(int i, double is, double th, double r, double pth, double pr, double &a, double &rs, double &am, double &rm) {
     a = th; rs = r;
-    double is = 1.0;
-    if constexpr (MODEL == MODEL_ILL_NORMAL) { is = p.md.aux[i]; a = a * is; rs = rs * is; }
+    if constexpr (MODEL == MODEL_ILL_NORMAL) { a = a * is; rs = rs * is; }
     if constexpr (MODEL == MODEL_AR1) {
         const double ca = 0.9, cb = sqrt(1 - ca * ca);
         if (i > 0) { a = (th - ca * pth) / cb; rs = (r - ca * pr) / cb; }
@@ -860,7 +880,7 @@ __device__ __forceinline__ double quad_max(double x) {
 // next direction's normals need only the RNG state after the MH draws, the direction pass only theta' (and, at a window
 // closure, the new mean / cov / eigenvectors).  Wavefront A runs the tail (MH scalars | T1 | CCIPCA or closure), wavefront B
 // the head (normals | direction + line sums), each with its own LDS column, meeting at three workgroup barriers:
-//   b1 after the MH scalars (A hands the RNG state over in LDS), b2 after T1 (theta' is in HBM), b3 after the tail —
+//   b1 after the MH scalars (A hands the RNG state over in LDS), a flag after T1 (theta' is in HBM: B waits, A goes on), b3 after the tail —
 // B's direction pass goes before b3 unless a chain of the workgroup closes a window.  Every chain's arithmetic is the
 // single-wavefront form's, operation for operation.
 template <int MODEL, bool OVERRELAX, int VARIANT, int W, int CHDIV = 4>
@@ -883,12 +903,14 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
     double *Zn = pair ? Z + (size_t)D * W : Z;                              // head: the normals (pair mode: a column of its own)
     double *zwi = lds + (size_t)p.stream_waves * D * W;
     uint64_t *zki = reinterpret_cast<uint64_t *>(zwi + 256);
-    // pair mode: per tile 4 x W words for the RNG hand-over, then one word per workgroup: a chain closes a window in this launch
+    // pair mode: per tile 4 x W words for the RNG hand-over, then four ints per workgroup: a chain closes a window in this launch | - |
+    // the T1 flags of its (up to two) tiles
     unsigned long long *hand = reinterpret_cast<unsigned long long *>(zwi + 512) + (size_t)tslot * 4 * W + cl;
     int *closing = reinterpret_cast<int *>(zwi + 512 + (size_t)tiles_wg * 4 * W);
+    int *t1_done = closing + 2 + tslot;                         // per tile: the tail's wavefront has stored theta' (pass T1)
     if ((do_head && (p.phases & PH_DIR)) || pair) {
         for (int i = tid; i < 256; i += blockDim.x) { zwi[i] = KLHR_ZIG_WI[i]; zki[i] = KLHR_ZIG_KI[i]; }
-        if (pair && tid == 0) *closing = 0;
+        if (pair && tid < 4) closing[tid] = 0;                 // (closing, -, t1_done of the workgroup's two tiles)
         __syncthreads();
     }
     // (a wavefront whose tile lies beyond the last chain ends here; s_barrier waits for the surviving wavefronts only)
@@ -1028,16 +1050,25 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
         KLHR_STAMP(st_t1);
     }
     // the D normals of the next direction (klhr_sinh.py:207-212; eigen_method_one: rng.choice() consumes one uniform BEFORE them).
-    // (64 lanes: a lane in the ziggurat's slow branch parks while the others go on; 16 lanes: the slow branch is rare
-    //  enough per wavefront-draw — 18 % — that the plain loop is faster, measured 64 k vs 89 k cycles per 100 normals)
+    // (64 lanes: a lane in the ziggurat's slow branch parks while the others go on; quad mode: the chain's four lanes draw four
+    //  normals per round from the generator's stride-4 recurrence — device_rng.hpp)
     auto draw_normals = [&]() {
         u_choice = (p.flags & FLAG_EIGEN_ONE) ? pcg_next_double(rng) : 0.0;
         if constexpr (W >= 32) rng_std_normal_column(rng, Zn, W, D, zwi, zki);
-        else { for (int k = 0; k < D; k++) Zn[k * W] = rng_std_normal_tab(rng, zwi, zki); }
+        else rng_std_normal_quad(rng, Zn, W, D, lane, zwi, zki);
     };
-    if (pair) {          // the head's wavefront draws the normals while the tail's runs T1; b2: theta' is in HBM
-        if (role == 1 && run_head && (p.phases & PH_DIR)) draw_normals();
-        __syncthreads();
+    if (pair) {
+        // the head's wavefront draws the normals while the tail's runs T1.  The head's direction pass needs theta'; the tail needs
+        // nothing from the head here, so instead of a barrier (the tail would wait out the normals before its CCIPCA) the tail
+        // raises a flag in LDS once theta' is stored (release: its stores are complete) and the head waits for it (acquire)
+        if (role == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __hip_atomic_store(t1_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            if (run_head && (p.phases & PH_DIR)) draw_normals();
+            while (__hip_atomic_load(t1_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
     }
     // pass 0: the rest of the tail; the head follows in pass 1 — in pair mode its wavefront runs it in pass 0 already, beside
     // the other wavefront's CCIPCA, unless a chain of the workgroup closes a window (mean / cov / eigenvectors / ranks change)
@@ -1099,7 +1130,7 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
         double m0l = 0, m1l = 0, nanl = 0;   // (quad mode: the lane's maxima)
         // one coordinate of the line sums (and of the direction's norm): lane = chain in index order as it comes; quad mode
         // element-wise on the lane's own coordinate, then the quad's four terms in index order
-        auto line_step = [&](auto full, auto with_n2, int step, int i, bool valid, double th, double r) {
+        auto line_step = [&](auto full, auto with_n2, int step, int i, bool valid, double th, double r, double is) {
             if constexpr (QN == 1) {
                 if constexpr (decltype(with_n2)::value) n2 += (r + p.tol) * (r + p.tol);
                 line_accumulate<MODEL>(p, i, th, r, st, Bs, Cs, m1, prev_th, prev_r);
@@ -1111,7 +1142,7 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
                     prev_th = quad_bcast<3>(th); prev_r = quad_bcast<3>(r);
                 }
                 double a, rs, am, rm;
-                line_elem<MODEL>(p, valid ? i : D - 1, th, r, pth, pr, a, rs, am, rm);
+                line_elem<MODEL>(i, is, th, r, pth, pr, a, rs, am, rm);
                 if (valid && !(MODEL == MODEL_FUNNEL && i == 0)) {
                     m0l = fmax(m0l, am); m1l = fmax(m1l, rm);
                     if (am != am || rm != rm) nanl = 1.0;
@@ -1142,6 +1173,7 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
                             const int ic = full || i < D ? i : D - 1;
                             b.m[k] = dm[ic * W]; b.s[k] = ds[ic * W];
                             b.rk[k] = rank[ic * W]; b.th[k] = theta[ic * W];
+                            b.is[k] = (QN > 1 && MODEL == MODEL_ILL_NORMAL) ? p.md.aux[ic] : 1.0;
                         }
                     },
                     [&](auto &b, int s0, auto full) {
@@ -1151,7 +1183,7 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
                             const bool valid = full || i < D;
                             const double r = b.m[k] + b.s[k] * Zn[b.rk[k] * W];
                             if (valid) rho[i * W] = r;
-                            line_step(full, std::true_type(), s0 + k, i, valid, b.th[k], r);
+                            line_step(full, std::true_type(), s0 + k, i, valid, b.th[k], r, b.is[k]);
                         }
                     });
             } else {
@@ -1189,6 +1221,7 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
                         b.e1[k] = nc > 1 ? evec[ic * es + W] : 0.0;
                         b.e2[k] = nc > 2 ? evec[ic * es + 2 * W] : 0.0;
                         b.cv[k] = cov[ic * W]; b.rk[k] = rank[ic * W]; b.th[k] = theta[ic * W];
+                        b.is[k] = (QN > 1 && MODEL == MODEL_ILL_NORMAL) ? p.md.aux[ic] : 1.0;
                     }
                 },
                 [&](auto &b, int s0, auto full) {
@@ -1207,7 +1240,7 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
                         }
                         const double r = m + sqrt(b.cv[k]) * Zn[b.rk[k] * W];
                         if (valid) rho[i * W] = r;
-                        line_step(full, std::true_type(), s0 + k, i, valid, b.th[k], r);
+                        line_step(full, std::true_type(), s0 + k, i, valid, b.th[k], r, b.is[k]);
                     }
                 });
             }
@@ -1228,7 +1261,7 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
                     const int i = s0 * QN + q;
                     const bool valid = i < D;
                     const int ic = valid ? i : D - 1;
-                    line_step(std::false_type(), std::false_type(), s0, i, valid, theta[ic * W], rho[ic * W]);
+                    line_step(std::false_type(), std::false_type(), s0, i, valid, theta[ic * W], rho[ic * W], MODEL == MODEL_ILL_NORMAL ? p.md.aux[ic] : 1.0);
                 }
             }
         }
@@ -1277,8 +1310,8 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
     }
 #ifdef KLHR_STAMPS
     KLHR_STAMP(st_fin);
-    if (lane == 0) {      // diagnostic build: cycle totals of this launch's phases, accumulated in the tile's first diag row
-        double *ds = p.d_diag + c * KLHR_NDIAG;
+    if (lane == 0) {      // diagnostic build: cycle totals of this launch's phases, accumulated in the tile's first diag row (pair mode: the head's wavefront in the second)
+        double *ds = p.d_diag + (c + (role == 1 ? 1 : 0)) * KLHR_NDIAG;
         ds[0] += (double)st_state; ds[1] += (double)st_mh; ds[2] += (double)st_t1; ds[3] += (double)st_pca; ds[4] += (double)st_norm;
         ds[5] += (double)st_dir; ds[6] += (double)st_fin; ds[7] += 1.0;
     }
@@ -1316,8 +1349,20 @@ __global__ __launch_bounds__(128, WAVES) void klhr_tile_kernel(const KParams p) 
         asm volatile("" : "+s"(bid));
         asm volatile("" : "+v"(tid));
         const long long task = (long long)bid * 16 + (tid >> 6) * 8 + ((tid & 63) >> 3);
+#ifdef KLHR_STAMPS
+        const unsigned long long tf0 = __builtin_readcyclecounter();
+#endif
         if (it < p.n_iters) fitn_body<MODEL, VARIANT>(p, task, tid & 7);
+#ifdef KLHR_STAMPS
+        const unsigned long long tf1 = __builtin_readcyclecounter();
+#endif
         __syncthreads();                 // eta and the evaluation counts are in HBM
+#ifdef KLHR_STAMPS
+        if ((tid & 63) == 0) {           // diagnostic build: the fit and the wait for the tile's other wavefront, fields 8 / 9 of the wavefront's row
+            double *ds = p.d_diag + ((long long)bid * 16 + (tid >> 6)) * KLHR_NDIAG;
+            ds[8] += (double)(tf1 - tf0); ds[9] += (double)(__builtin_readcyclecounter() - tf1);
+        }
+#endif
     }
 }
 #pragma clang fp contract(fast)

@@ -14,7 +14,10 @@ s.set("diag", np.zeros((C,_lib.NDIAG)))
 N=20
 s.step(N)
 d=s.get("diag")
-rows=d[d[:,7]>0]
+tw=16 if "tile" in s.kernel_name() or "stream16" in s.kernel_name() else 64
+print(s.kernel_name())
+heads=d[1::tw]; heads=heads[heads[:,7]>0]           # pair mode: the head's wavefront reports in the tile's second row
+rows=d[0::tw]; rows=rows[rows[:,7]>0]
 names=["load state","MH scalars","T1 (theta', moments, u)","CCIPCA / closure","normals","direction + line sums + fit normals","store state"]
 tot=rows[:,:7].sum(axis=1).mean()
 print(f"{model}-{D} x {C}: {len(rows)} tiles, {rows[:,7].mean():.0f} launches each")
@@ -22,3 +25,10 @@ for k,n in enumerate(names):
     v=rows[:,k].mean()
     print(f"{n:40s} {v/N:12.0f} cycles per iteration  ({100*v/tot:5.1f} %)")
 print("cycles per iteration", tot/N)
+if len(heads):
+    print("pair mode, the head's wavefront:")
+    for k,n in enumerate(names):
+        print(f"{n:40s} {heads[:,k].mean()/N:12.0f} cycles per iteration")
+if rows[:,8].any():
+    print(f"tile kernel: fit {rows[:,8].mean()/N:.0f} cycles per iteration, wait for the tile's other wavefront after it {rows[:,9].mean()/N:.0f}")
+    if len(heads): print(f"             second wavefront: fit {heads[:,8].mean()/N:.0f}, wait {heads[:,9].mean()/N:.0f}")
