@@ -103,6 +103,7 @@ struct klhr_sampler {
     int comm_rank = 0, comm_world = 0;
     bool fitn = false;           // split pipeline: both fit stages in the node-parallel kernel (few chains: klhr_fitn_kernel)
     bool last_fused = false;     // the most recent klhr_step ran as one klhr_tile_kernel launch
+    long long small_max = 16384; // split pipeline: up to this many chains 16-chain tiles and the tile kernel
     bool fused = false;          // split pipeline, few chains: whole iterations per tile in one launch (klhr_tile_kernel)
     bool profile = false;
     std::vector<hipEvent_t> pev;
@@ -375,7 +376,12 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
         // as one wavefront's walk through its phases whatever the width, and 16-chain tiles can run a tile's tail and head
         // on two wavefronts (pair mode below, up to 16 384 chains).  Measured, ill-normal-100 (us per iteration, 16 | 64):
         // 32 768 chains 299 | 270, 65 536: 642 | 420, 131 072: 1 114 | 644.
-        int tw = s->C <= 16384 ? 16 : 64;
+        // (16-chain tiles are the tile kernel's: whole iterations per tile, quad mode.  Against the 64-chain kernel sequence it wins up to
+        //  16 384 chains on every target and up to 32 768 on the Gaussian ones, whose fits are short — measured, us per iteration,
+        //  sequence | tile kernel: ill-normal-100 x 24 576: 221 | 188, x 32 768: 266 | 194; funnel-100 x 24 576: 373 | 330, x 32 768: 409 | 420;
+        //  funnel-50 x 32 768: 317 | 359)
+        s->small_max = cfg->model_id == KLHR_MODEL_FUNNEL ? 16384 : 32768;
+        int tw = s->C <= s->small_max ? 16 : 64;
         if (const char *e = getenv("KLHR_TILE")) { const int v = atoi(e); if (v == 16 || v == 64) tw = v; }
         if (((size_t)D * tw + 512) * 8 > 160 * 1024) tw = 16;       // (one column block + the tables must fit a CU's LDS)
         s->tw = tw;
@@ -415,9 +421,10 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
         if (const char *e = getenv("KLHR_FITN")) s->fitn = atoi(e) != 0;
         // few chains: klhr_step runs whole iterations per 16-chain tile in ONE launch (klhr_tile_kernel: the pair-mode streaming
         // body and the node-parallel fit body in a loop over the draws, one workgroup per tile).  Needs what those two need.
-        // Up to 16 384 chains (2 048 wavefronts: two per SIMD, the kernel's 256-register build); measured in klhr_split.hpp.
+        // Up to 16 384 chains all tiles are resident (2 048 wavefronts: two per SIMD, the kernel's 256-register build; measured in
+        // klhr_split.hpp); Gaussian targets up to 32 768 (a second round of workgroups, see the tile width above).
         const bool fused_ok = s->tw == 16 && s->fitn && ((size_t)2 * D * 16 + 512 + 66) * 8 <= 160 * 1024;
-        long long fused_max = 16384;
+        long long fused_max = s->small_max;
         if (const char *e = getenv("KLHR_FUSED_MAX")) fused_max = atoll(e);                  // (tuning aid)
         s->fused = fused_ok && s->C <= fused_max;
         if (const char *e = getenv("KLHR_FUSED")) s->fused = s->fused && atoi(e) != 0;      // (0: the kernel sequence; used by the parity tests)
