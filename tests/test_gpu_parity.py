@@ -885,3 +885,50 @@ def test_exact_patch_draws_vs_oracle(oracle, monkeypatch, kernel_mode, name, for
     assert np.mean(e < 1e-9) >= 0.95, (name, form, np.sort(e)[-8:])
     moved = np.abs(want - cat("theta")).max(axis=1) + np.abs(th - cat("theta")).max(axis=1)
     assert np.all(e <= 1e-9 + 2.0 * moved), (name, form)
+
+
+@pytest.mark.parametrize("form", ["tile", "fitn"])
+@pytest.mark.parametrize("stem,D", [("funnel", 5), ("funnel", 27), ("ill-normal", 30), ("ar1", 33), ("normal", 41), ("ill-normal", 103)])
+def test_quad_mode_ragged_dimensions(oracle, monkeypatch, kernel_mode, stem, D, form):
+    """Quad mode of the 16-chain tiles (four lanes per chain, coordinate i = 4 step + q; klhr_split.hpp) at dimensions that are NOT
+    multiples of four (a last, partial step; D = 5: one whole step), on every separable target, through two window closures (the
+    rank rule, the column norms and the direction cache are written by four lanes per chain) and with the direction's normals
+    drawn four per round from the generator's stride-4 recurrence (device_rng.hpp: rng_std_normal_quad).
+    (a) Against lane = chain (64-chain tiles, the same pipeline without quad mode): every draw, the generator and the whole
+    adaptation state are the SAME BITS.  (b) Against the oracle up to the first closure: generator position exact, theta within 1e-9
+    (beyond a closure the comparison says nothing about the mapping: with 20-draw windows CCIPCA's first updates — weights
+    (n - 1 - l) / n < 0 for n <= 4 — amplify the fit's rounding-level differences to 1e-6 in the eigenvectors, for the monolithic
+    kernels just the same)."""
+    if kernel_mode != "auto":
+        pytest.skip("this test selects the forms itself")
+    data = {"N": D} if stem == "ar1" else {"D": D}
+    kw = dict(warmup=60, windowsize=20)
+    C, n = 20, 70
+    seeds = np.arange(C, dtype=np.uint64) + 5200 + D
+    fields = STATE_FIELDS + ["acc", "grad_evals", "counters"]
+
+    def run(env, nd):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        s = make_sampler(stem, data, C, **kw)
+        s.seed(seeds)
+        s.step(nd, record_draws=True)
+        assert not s.get("status").any()
+        return s.kernel_name(), s.draws(0, nd), {f: s.get(f) for f in fields}
+
+    name64, d64, st64 = run({"KLHR_KERNEL": "split", "KLHR_FITN": "1", "KLHR_FUSED": "0", "KLHR_TILE": "64"}, n)
+    assert "klhr_stream_kernel" in name64, name64
+    nameq, dq, stq = run(dict(SPLIT_FORMS[form], KLHR_TILE="16"), n)
+    assert ("tile" in nameq) == (form == "tile") and ("stream16" in nameq) == (form != "tile"), nameq
+    assert np.array_equal(dq, d64), (stem, D, form, int(np.argmax((dq != d64).any(axis=(1, 2)))))
+    for f in fields:
+        assert np.array_equal(stq[f], st64[f]), (stem, D, form, f)
+    # (b) the oracle, up to the first closure (draw 20)
+    m = 19
+    chains = [oracle.Chain(stem, data, seed=int(sd), **kw) for sd in seeds]
+    ref = np.array([c.draw_many(m) for c in chains]).transpose(1, 0, 2)
+    _, dm, stm = run(dict(SPLIT_FORMS[form], KLHR_TILE="16"), m)
+    assert np.array_equal(stm["rng"], np.array([c.get("rng") for c in chains])), (stem, D, form)
+    err = np.abs(dm - ref).max(axis=2) / (1.0 + np.abs(ref).max(axis=2))
+    bad = (err > 1e-9).any(axis=0)
+    assert bad.sum() <= (2 if stem != "ar1" else C // 2), (stem, D, form, err.max(axis=0))
