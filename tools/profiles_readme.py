@@ -45,7 +45,7 @@ s = s[:i] + txt + s[j:]
 # ---- round 3: the four BASELINE configurations on the final build of the round, every traffic.json entry tied to its build id
 import json
 R3 = {"r03_lane_f10": "funnel-10 × 65 536 (headline), lane kernel", "r03_split_f100": "funnel-100 × 131 072, split pipeline (direction cache), `KLHR_GROUPS=1`",
-      "r03_split_ill": "ill-normal-100 × 16 384, split pipeline (pair-mode streaming, node-parallel fit), `KLHR_GROUPS=1`",
+      "r03_tile_ill": "ill-normal-100 × 16 384, tile kernel (whole iterations per 16-chain tile: quad-mode streaming body + node-parallel fit body, 50 draws per launch)",
       "r03_octet_glmm": "glmm-poisson-45 × 8 192, octet kernel"}
 tj = json.load(open("profiles/traffic.json"))
 t3 = "\n\n## Round 3 (`r03_*`): the four BASELINE configurations on the round's final build\n\n"
