@@ -223,3 +223,31 @@ def test_window_closures_degenerate_schedules(lib):
     # extreme arguments terminate too (128-bit intermediates): no hang, no overflow
     assert lib.window_closures(2**62, 1, 2**31) == [1, 2**62]        # 1 + 2^31 * 2^31 >= warmup: the second window runs to warmup
     assert len(lib.window_closures(2**62, 2**40, 3)) < 64
+
+
+def test_pcg64_jump_constants_of_the_quad_generator():
+    """device_rng.hpp: rng_std_normal_quad advances PCG64's 128-bit LCG q + 1 and 4 steps at a time: state * M^k + inc * G_k with
+    G_k = 1 + M + ... + M^(k-1).  The constants in the header must be those powers / sums of NumPy's multiplier (mod 2^128), and
+    k single steps must equal one jump for an arbitrary state and increment."""
+    import re
+    src = open(os.path.join(ROOT, "klhr_amd", "csrc", "device_rng.hpp")).read()
+    body = src[src.index("rng_std_normal_quad(Pcg64 &g"):]
+    val = {}
+    for name, hi, lo in re.findall(r"\b([MG][1-4]) = \(\(\(u128\)0x([0-9A-Fa-f]+)ULL\) << 64\) \| \(u128\)0x([0-9A-Fa-f]+)ULL", body):
+        val[name] = (int(hi, 16) << 64) | int(lo, 16)
+    assert re.search(r"\bG1 = 1\b", body)
+    val["G1"] = 1
+    assert sorted(val) == ["G1", "G2", "G3", "G4", "M1", "M2", "M3", "M4"], sorted(val)
+    mod = 1 << 128
+    M = (0x2360ED051FC65DA4 << 64) | 0x4385DF649FCCF645          # numpy/random/src/pcg64/pcg64.h: PCG_DEFAULT_MULTIPLIER
+    assert val["M1"] == M
+    g = 0
+    for k in range(1, 5):
+        g = (g * M + 1) % mod
+        assert val[f"M{k}"] == pow(M, k, mod), k
+        assert val[f"G{k}"] == g, k
+    state, inc = 0x0123456789ABCDEF_FEDCBA9876543210, (0x9E3779B97F4A7C15_F39CC0605CEDC835 | 1)
+    t = state
+    for k in range(1, 5):
+        t = (t * M + inc) % mod
+        assert t == (state * val[f"M{k}"] + inc * val[f"G{k}"]) % mod
