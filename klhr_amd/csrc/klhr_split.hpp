@@ -938,43 +938,24 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
     // =================================================================== tail of iteration k (klhr_sinh.py:266-287)
     const bool tail_here = run_tail && role != 1, head_here = run_head && role != 0;
     const bool mh = (p.phases & PH_MH) != 0, adapt = (p.phases & PH_ADAPT) != 0;
-    double zp = 0.0, ad = 0.0, na = 1.0, nn = 1.0, w = 1.0;
+    double zp = 0.0, ad = 0.0, na = 1.0, nn = 1.0, w = 1.0, z0 = 0.0, u01 = 0.0;
+    double eta[4] = {0, 0, 0, 0};
     bool closed = false, upd = false, closing_any = false;
     if (tail_here) {
         // grad_evals += nfev1 + 8 nfev2 of the fit that preceded this tail (klhr_sinh.py:188,200)
         if (own && (p.phases & PH_FIT)) p.grad_evals[c] += (long long)KLHR_FB(p, F_NFEV1, c) + 8 * (long long)KLHR_FB(p, F_NFEV2, c);
+        // the generator first: the proposal's variate(s) and the accept test's uniform are consecutive in the chain's stream (nothing between
+        // them draws), so the head's wavefront can take the generator over before the MH scalars are worked out
         if (mh) {
-            const LineStat st = load_stat(p, c);
-            nn = KLHR_FB(p, F_NN, c);
-            double eta[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) eta[k] = p.d_eta[c * 4 + k];
             draw += 1;
             if constexpr (VARIANT == VAR_GAUSS && OVERRELAX) { const ZpOut zo = gauss_overrelaxed_zp_call(rng, eta[0], eta[1], Kc, p.scale_clip); zp = zo.zp; rng = zo.rng; }
             else if constexpr (VARIANT == VAR_GAUSS) zp = gauss_zp<false>(rng, eta, Kc, p.scale_clip);
             else if constexpr (OVERRELAX) { const ZpOut zo = overrelaxed_zp_call(rng, eta[0], eta[1], eta[2], eta[3], p.K, p.tol, p.scale_clip, VARIANT == VAR_SUB); zp = zo.zp; rng = zo.rng; }
-            else zp = sa_T(rng_std_normal_call(rng), eta, p.tol, p.scale_clip, VARIANT == VAR_SUB);
-            double lp_p, lp_c, gd_;
-            (void)line_point<MODEL, false>(p, st, zp, INFINITY, lp_p, gd_);
-            (void)line_point<MODEL, false>(p, st, 0.0, INFINITY, lp_c, gd_);
-            double r = lp_p;
-            r -= lp_c;
-            if constexpr (VARIANT == VAR_GAUSS) {
-                const double gm = eta[0], gs = exp(clipc(eta[1], p.scale_clip));
-                r += gauss_logq(0.0, gm, gs);
-                r -= gauss_logq(zp, gm, gs);
-            } else {
-                r += sa_log_q(0.0, eta, p.tol, p.scale_clip, VARIANT == VAR_SUB);
-                r -= sa_log_q(zp, eta, p.tol, p.scale_clip, VARIANT == VAR_SUB);
-            }
-            const double logu = log(rng_uniform(rng));
-            const double mn = (r != r) ? r : (r < 0 ? r : 0.0);      // np.minimum(0, r)
-            const int a = logu < mn ? 1 : 0;
-            ad = (double)a; na = (double)(1 - a);
-            acc += (ad - acc) / (double)draw;
-            if (diag && own) { double *dd = p.d_diag + c * KLHR_NDIAG; dd[KLHR_D_ZP] = zp; dd[KLHR_D_R] = r; dd[KLHR_D_LOGU] = logu; dd[KLHR_D_ACCEPT] = a; }
+            else z0 = rng_std_normal_call(rng);
+            u01 = rng_uniform(rng);
         }
-        KLHR_STAMP(st_mh);
         if (adapt && !(p.warmup < p.windowsize) && p.nclos > 0) {
             closed = draw == p.closures[cidx];
             if (closed && cidx < p.nclos - 1) cidx++;
@@ -993,6 +974,33 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
             rng.sh = hand[0]; rng.sl = hand[W]; rng.ih = hand[2 * W]; rng.il = hand[3 * W];
             closing_any = *closing != 0;
         }
+    }
+    if (tail_here) {
+        if (mh) {
+            const LineStat st = load_stat(p, c);
+            nn = KLHR_FB(p, F_NN, c);
+            if constexpr (VARIANT != VAR_GAUSS && !OVERRELAX) zp = sa_T(z0, eta, p.tol, p.scale_clip, VARIANT == VAR_SUB);
+            double lp_p, lp_c, gd_;
+            (void)line_point<MODEL, false>(p, st, zp, INFINITY, lp_p, gd_);
+            (void)line_point<MODEL, false>(p, st, 0.0, INFINITY, lp_c, gd_);
+            double r = lp_p;
+            r -= lp_c;
+            if constexpr (VARIANT == VAR_GAUSS) {
+                const double gm = eta[0], gs = exp(clipc(eta[1], p.scale_clip));
+                r += gauss_logq(0.0, gm, gs);
+                r -= gauss_logq(zp, gm, gs);
+            } else {
+                r += sa_log_q(0.0, eta, p.tol, p.scale_clip, VARIANT == VAR_SUB);
+                r -= sa_log_q(zp, eta, p.tol, p.scale_clip, VARIANT == VAR_SUB);
+            }
+            const double logu = log(u01);
+            const double mn = (r != r) ? r : (r < 0 ? r : 0.0);      // np.minimum(0, r)
+            const int a = logu < mn ? 1 : 0;
+            ad = (double)a; na = (double)(1 - a);
+            acc += (ad - acc) / (double)draw;
+            if (diag && own) { double *dd = p.d_diag + c * KLHR_NDIAG; dd[KLHR_D_ZP] = zp; dd[KLHR_D_R] = r; dd[KLHR_D_LOGU] = logu; dd[KLHR_D_ACCEPT] = a; }
+        }
+        KLHR_STAMP(st_mh);
     }
     double u_choice = 0.0, ssq = 0.0;
     if (tail_here) {
