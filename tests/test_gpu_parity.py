@@ -932,3 +932,39 @@ def test_quad_mode_ragged_dimensions(oracle, monkeypatch, kernel_mode, stem, D, 
     err = np.abs(dm - ref).max(axis=2) / (1.0 + np.abs(ref).max(axis=2))
     bad = (err > 1e-9).any(axis=0)
     assert bad.sum() <= (2 if stem != "ar1" else C // 2), (stem, D, form, err.max(axis=0))
+
+
+@pytest.mark.parametrize("opts", [dict(variant=1), dict(variant=1, overrelaxed=True), dict(variant=2), dict(overrelaxed=True), dict(scale_dir_cov=True),
+                                  dict(eigen_method_one=True), dict(J=3), dict(J=1)],
+                         ids=["klhr", "klhr-overrelaxed", "sub", "overrelaxed", "scale_dir_cov", "eigen_method_one", "J3", "J1"])
+@pytest.mark.parametrize("stem,D", [("funnel", 27), ("ill-normal", 30)])
+def test_quad_mode_variants_and_flags_equal_lane_per_chain(monkeypatch, kernel_mode, stem, D, opts):
+    """Every sampler variant and flag of the split pipeline through quad mode (16-chain tiles: the tile kernel AND the kernel sequence
+    in pair mode) at a dimension with a partial last step, against lane = chain (64-chain tiles): 70 draws through two closures, the
+    same draws, generator and adaptation state bit for bit.  (KLHR's Smoother state, the gradient's OnlineMoments of scale_dir_cov,
+    rng.choice()'s uniform ahead of the quad generator's rounds, one and three CCIPCA components.)"""
+    if kernel_mode != "auto":
+        pytest.skip("this test selects the forms itself")
+    data = {"D": D}
+    kw = dict(warmup=60, windowsize=20, **opts)
+    C, n = 20, 70
+    seeds = np.arange(C, dtype=np.uint64) + 6100 + D
+    fields = STATE_FIELDS + ["acc", "grad_evals", "counters"]
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        s = make_sampler(stem, data, C, **kw)
+        s.seed(seeds)
+        s.step(n, record_draws=True)
+        return s.kernel_name(), s.draws(0, n), {f: s.get(f) for f in fields}, s.get("status")
+
+    name64, d64, st64, status64 = run({"KLHR_KERNEL": "split", "KLHR_FITN": "1", "KLHR_FUSED": "0", "KLHR_TILE": "64"})
+    assert "klhr_stream_kernel" in name64, name64
+    for form in ("tile", "fitn"):
+        nameq, dq, stq, statusq = run(dict(SPLIT_FORMS[form], KLHR_TILE="16"))
+        assert ("tile" in nameq) == (form == "tile") and ("stream16" in nameq) == (form != "tile"), nameq
+        assert np.array_equal(statusq, status64), (stem, D, opts, form)
+        assert np.array_equal(dq, d64, equal_nan=True), (stem, D, opts, form, int(np.argmax((dq != d64).any(axis=(1, 2)))))
+        for f in fields:
+            assert np.array_equal(stq[f], st64[f], equal_nan=True), (stem, D, opts, form, f)
