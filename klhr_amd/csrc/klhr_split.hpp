@@ -657,7 +657,7 @@ __device__ __forceinline__ void seq_each(int step, int D, F f, T... v) {
 }
 template <int N> struct Buf1 { static constexpr int n = N; double v[N]; };
 template <int N> struct Buf2 { static constexpr int n = N; double v[N], q[N]; };
-template <int N> struct BufT1 { static constexpr int n = N; double th[N], rr[N], mm[N], vv[N], mn[N], v0[N]; };
+template <int N> struct BufT1 { static constexpr int n = N; double th[N], rr[N], mm[N], vv[N], mn[N]; };
 template <int N> struct BufDir { static constexpr int n = N; double e0[N], e1[N], e2[N], cv[N], th[N], is[N]; int rk[N]; };
 template <int N> struct BufDirC { static constexpr int n = N; double m[N], s[N], th[N], is[N]; int rk[N]; };
 
@@ -667,15 +667,13 @@ template <int N> struct BufDirC { static constexpr int n = N; double m[N], s[N],
 // pca_v rows.  Per component: sums (s, u.v) -> v' = w v + (1-w) u (u.v)/(|v|+tol), sums on v' -> u -= (u.v') v'/(|v'|^2+tol);
 // the deflation pass of component j also gathers the first sums of component j+1.  q: the lane's phase in quad mode (0 otherwise).
 template <int W, int CHDIV>
-__device__ inline void split_pca_update(const KParams &p, double *V, long long n_new, double *Z, const int q, const bool have_sums0, const double sum_s0,
-                                        const double sum_udv0) {
+__device__ inline void split_pca_update(const KParams &p, double *V, long long n_new, double *Z, const int q) {
     constexpr int QN = W == 16 ? 4 : 1;
     const int D = p.D, K = p.J;
     const long long lim = n_new < K ? n_new : K;
     const long long vs = (long long)K * W;
-    // (have_sums0: pass T1 gathered component 0's sums |v|^2 and u.v while it formed u — the same terms in the same order)
-    double s = sum_s0, udv = sum_udv0;
-    bool have_sums = have_sums0;
+    double s = 0, udv = 0;
+    bool have_sums = false;
     for (int col = 0; col < lim; col++) {
         double *Vc = V + (long long)col * W;
         if (col == n_new - 1) {
@@ -1004,8 +1002,7 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
         }
         KLHR_STAMP(st_mh);
     }
-    double u_choice = 0.0, ssq = 0.0, pca_s0 = 0.0, pca_udv0 = 0.0;
-    bool pca_sums0 = false;
+    double u_choice = 0.0, ssq = 0.0;
     if (tail_here) {
         double *out = p.draws ? p.draws + (long long)draw_slot * p.draw_stride + c * D : nullptr;
         // ---- pass T1: theta' = a (theta + zp rho) + (1 - a) theta; OnlineMoments(theta'); Z = theta' - mean
@@ -1013,11 +1010,6 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
         bool fin = true;
         double *const om_m = p.om_m + tb, *const om_v = p.om_v + tb;
         const double *const mean = p.mean + tb;
-        // CCIPCA's first pass — component 0's |v|^2 and u.v — rides on this one (u is formed here): one walk over D and one read of
-        // the column less per draw.  Only when component 0 is updated by this draw (from the window's second draw on).
-        const double *const pv0 = p.pca_v + tbv;
-        const long long pvs = (long long)K * W;
-        pca_sums0 = upd && K > 0 && pcan + 1 >= 2;
         for_chunks_pipelined<ST_CH, BufT1, QN>(D,
             [&](auto &b, int s0, auto full) {
 #pragma unroll
@@ -1027,7 +1019,6 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
                     b.th[k] = theta[ic * W];
                     b.rr[k] = mh ? rho[ic * W] : 0.0;
                     if (upd) { b.mm[k] = om_m[ic * W]; b.vv[k] = om_v[ic * W]; b.mn[k] = mean[ic * W]; }
-                    if (pca_sums0) b.v0[k] = pv0[ic * pvs];
                 }
             },
             [&](auto &b, int s0, auto full) {
@@ -1054,13 +1045,11 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
                         const double d = nx - mi;
                         mi += d * w;
                         vi += -vi * w + d * d * w * (1 - w);
-                        const double u = nx - b.mn[k];
                         if (valid) {
                             om_m[i * W] = mi;
                             om_v[i * W] = vi;
-                            Z[i * W] = u;
+                            Z[i * W] = nx - b.mn[k];
                         }
-                        if (pca_sums0) seq_each<QN, decltype(full)::value>(s0 + k, D, [&](int, double vv, double zv) { pca_s0 += vv; pca_udv0 += zv; }, b.v0[k] * b.v0[k], u * b.v0[k]);
                     }
                 }
             });
@@ -1134,7 +1123,7 @@ __device__ __forceinline__ void stream_body(const KParams &p, const int do_tail,
                 });
             }
             pcan += 1;
-            split_pca_update<W, CHDIV>(p, p.pca_v + tbv, pcan, Z, q, pca_sums0, pca_s0, pca_udv0);
+            split_pca_update<W, CHDIV>(p, p.pca_v + tbv, pcan, Z, q);
         }
         KLHR_STAMP(st_pca);
     }
