@@ -99,12 +99,12 @@ KLHR_API int klhr_sync(klhr_sampler *s);                       /* wait for the h
  * (klhr_lane_kernel, model dimension <= 26), 2 = split-phase pipeline: streaming kernel + klhr_fit12_kernel (both fit
  * stages lane = chain; funnel / ill-normal / normal / ar1 above dimension 26), 3 = split-phase pipeline with both fit
  * stages in the node-parallel klhr_fitn_kernel (up to 32 768 chains), 5 = as 3, and klhr_step runs whole iterations per
- * 16-chain tile in one launch (klhr_tile_kernel, up to 8 192 chains; the pieces of the C ABI and diagnostic steps use
- * the kernels of 3).  (4 was the hand-over mode removed in round 3.)  Results agree within the stated tolerances
+ * 16-chain tile in one launch (klhr_tile_kernel: up to 16 384 chains, ill-normal / normal / ar1 up to 32 768; the pieces
+ * of the C ABI and diagnostic steps use the kernels of 3).  (4 was the hand-over mode removed in round 3.)  Results agree within the stated tolerances
  * (2, 3, 5: bit for bit); only the mapping to the machine differs.  KLHR_KERNEL = octet | lane | mono | split in the
  * environment overrides.
  * klhr_tile_width: chains per tile of the split pipeline's state layout — 64 (klhr_stream_kernel) or 16
- * (klhr_stream16_kernel, up to 16 384 chains); 0 for the monolithic kernels. */
+ * (klhr_stream16_kernel / klhr_tile_kernel, four lanes per chain; the range of variant 5); 0 for the monolithic kernels. */
 KLHR_API int klhr_kernel_variant(const klhr_sampler *s);
 KLHR_API int klhr_tile_width(const klhr_sampler *s);
 

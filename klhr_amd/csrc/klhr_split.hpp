@@ -10,7 +10,8 @@
 // reference: 1 in 2 000-5 000 KL evaluations) is recomputed by the exact element-wise loop, so clipping semantics are kept.
 //
 // With the fit reduced to O(1) state per chain the iteration splits into two kernels with the mapping each part wants:
-//   klhr_stream_kernel  lane = chain, wavefront = tile of 64 (or 16) chains.  Everything that is O(D) per chain and sequential
+//   klhr_stream_kernel  lane = chain, wavefront = tile of 64 chains (klhr_stream16_kernel: tiles of 16 chains, FOUR lanes per chain
+//                       — quad mode, below).  Everything that is O(D) per chain and sequential
 //                       in the coordinate index (NumPy's summation orders, the PCG64 stream): MH accept/reject + theta
 //                       update + OnlineMoments + CCIPCA (+ window closure) of iteration k, then the direction draw, the
 //                       line sums and the fit's five normals of iteration k+1.  The chain state lives in HBM in a TILED
@@ -19,7 +20,8 @@
 //   klhr_fit12_kernel   (many chains) lane = chain: the 1-D mode search (klhr_sinh.py:183-187, opt_advance<N = 1>), then the KL
 //                       fit (klhr_sinh.py:194-199, opt_advance<N = 4 | 3 | 2>, 8 Gauss-Hermite nodes per lane)
 //   klhr_fitn_kernel    (few chains) the same two stages with 8 lanes per chain, one quadrature node each
-//   klhr_tile_kernel    (fewest chains) whole iterations of a 16-chain tile — streaming body + node-parallel fit body — in one launch
+//   klhr_tile_kernel    (up to 16 384 chains; Gaussian targets 32 768) whole iterations of a 16-chain tile — quad-mode streaming body
+//                       on two wavefronts (tail | head) + node-parallel fit body — in one launch
 // Results: RNG stream, direction, OnlineMoments, CCIPCA, closures bit-exact as in the monolithic kernels; objective values
 // agree with the element-wise loops to rounding (closed form instead of a D-term sum), inside the stated tolerances.
 #pragma once
@@ -880,7 +882,7 @@ __device__ __forceinline__ double quad_max(double x) {
 // next direction's normals need only the RNG state after the MH draws, the direction pass only theta' (and, at a window
 // closure, the new mean / cov / eigenvectors).  Wavefront A runs the tail (MH scalars | T1 | CCIPCA or closure), wavefront B
 // the head (normals | direction + line sums), each with its own LDS column, meeting at three workgroup barriers:
-//   b1 after the MH scalars (A hands the RNG state over in LDS), a flag after T1 (theta' is in HBM: B waits, A goes on), b3 after the tail —
+//   b1 after the MH step's draws (A hands the RNG state over in LDS; its scalars follow), a flag after T1 (theta' is in HBM: B waits, A goes on), b3 after the tail —
 // B's direction pass goes before b3 unless a chain of the workgroup closes a window.  Every chain's arithmetic is the
 // single-wavefront form's, operation for operation.
 template <int MODEL, bool OVERRELAX, int VARIANT, int W, int CHDIV = 4>
@@ -1340,9 +1342,10 @@ __global__ __launch_bounds__(256, 2) void klhr_stream16_kernel(const KParams p, 
 // lanes per chain, 8 chains per wavefront), and nothing of an iteration crosses tiles — so the workgroup loops over the
 // iterations on its own: no launch boundaries, no wait for the slowest chain of the whole launch (a tile waits for the slowest
 // of its 16), and tiles drift apart, so that some stream (memory) while others fit (ALU).  Streaming and fit code are the
-// kernels' own bodies.  Two builds: WAVES = 1 wavefront per SIMD (308 registers, up to 8 192 chains = 512 tiles = 1 024
+// kernels' own bodies.  Two builds: WAVES = 1 wavefront per SIMD (360-380 registers, up to 8 192 chains = 512 tiles = 1 024
 // wavefronts) and WAVES = 2 (256 registers: the streaming body with half the chunk, 64-220 bytes of scratch; 8 193-16 384 chains).
-// ill-normal-100, us per iteration, kernel sequence | this kernel: 2 048 chains 137 | 88, 8 192: 154 | 94, 16 384: 139 | 121.
+// ill-normal-100, us per iteration, round 2's kernel sequence | this kernel: 2 048 chains 137 | 66, 8 192: 154 | 70, 16 384: 160 | 97
+// (the kernel sequence with quad mode: 122).
 template <int MODEL, bool OVERRELAX, int VARIANT, int WAVES>
 __global__ __launch_bounds__(128, WAVES) void klhr_tile_kernel(const KParams p) {
 #pragma unroll 1
