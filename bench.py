@@ -362,8 +362,7 @@ def main():
     rccl_failed = None
     if world > 1 and not args.no_configs:
         # every rank takes part (the collective needs them all); rank 0 reports.  A collective that never returns must not take the
-        # headline with it: a watchdog prints the line measured so far (with rccl.error) and ends the process.  The headline metric
-        # needs no collective, so a failure of this add-on is reported in the line (rccl.error) and on stderr, not through the exit code.
+        # headline with it: a watchdog prints the line measured so far (with rccl.error) and ends the process with a non-zero code.
         import threading
 
         def give_up():
@@ -371,7 +370,7 @@ def main():
                 out["rccl"] = {"error": f"the pooled shard (RCCL communicator / all-reduce over {world} ranks) did not finish within {POOLED_TIMEOUT_S} s"}
                 print(json.dumps(out), flush=True)
                 print("bench.py: the pooled shard's collective did not finish; see rccl.error in the line", file=sys.stderr, flush=True)
-            os._exit(0)
+            os._exit(3)
         watchdog = threading.Timer(POOLED_TIMEOUT_S, give_up)
         watchdog.daemon = True
         watchdog.start()
@@ -389,7 +388,7 @@ def main():
             out.setdefault("configs", {})["funnel-100x131072-per-gpu-pooled-full"] = {
                 "it_per_s": pr["value"], "ms_per_step": pr["ms_per_step"], "timed_regions": 3, "steps": 50, "kernel": pr["kernel"],
                 "chains_total": 131072 * world, "pooled": "full", "roofline": {k: pr["roofline"][k] for k in ("achieved", "frac", "kernel", "launch_ms", "kernels", "whole_iteration")}}
-        except Exception as e:          # reported in the line (rccl.error) and on stderr
+        except Exception as e:          # reported in the line (rccl.error), on stderr AND through the exit code
             rccl_failed = f"{type(e).__name__}: {e}"
             out["rccl"] = {"error": rccl_failed}
         watchdog.cancel()
@@ -452,6 +451,7 @@ def main():
         dist.destroy_process_group()
     if rccl_failed:
         print(f"bench.py: the pooled shard's collective did not run over all ranks: {rccl_failed}", file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":
