@@ -68,7 +68,10 @@ for k, v in tj.items():
     if "build_id" in v:
         t3 += (f"| `{k}` | `{v['kernel'].replace('void klhr::', '')}` | {v['hbm_bytes_per_launch']/1e9:.3f} GB | {v['algorithmic_bytes_per_launch']/1e9:.3f} GB | "
                f"{v['hbm_bytes_per_launch']/v['algorithmic_bytes_per_launch']:.2f} | {v['fp64_flops_per_launch']/1e9:.1f} | {v['rocprof_ms_per_iteration_all_kernels']:.4f} vs {v['bench_ms_per_step_when_profiled']:.4f} |\n")
-t3 += ("\n`r03_stamps/`: cycle split and bench of the free-running octet kernel (built, measured slower, removed: DESIGN.md §8).  `r03_experiments/`: `klhr_fit12_kernel` with a pass cap "
+t3 += ("\n`r03_stamps/`: `tile_kernel_cycle_split.txt` — per-phase cycles of the tile kernel's two wavefronts and of its fit (ill-normal-100 x 16 384 / 8 192, funnel-100 x 16 384) and of "
+       "the single-wavefront 16-chain streaming kernel, from a `-DKLHR_STAMPS` build checked bit for bit against the production library (`tools/stamps_tile.sh`); cycle split and "
+       "bench of the free-running octet kernel (built, measured slower, removed: DESIGN.md §8).  `r03_experiments/`: `t1_pca_fusion.txt` (CCIPCA's first pass fused into T1: bit-identical, "
+       "0-1 %, no traffic saved: reverted); `klhr_fit12_kernel` with a pass cap "
        "(what the KL fits' tail costs) and with straggler compaction in several workgroup / register configurations, funnel-100 × 131 072, same box back to back.\n")
 k3 = "\n\n## Round 3 (`r03_*`)"
 if k3 in s:
