@@ -888,10 +888,10 @@ def test_exact_patch_draws_vs_oracle(oracle, monkeypatch, kernel_mode, name, for
 
 
 @pytest.mark.parametrize("form", ["tile", "fitn"])
-@pytest.mark.parametrize("stem,D", [("funnel", 5), ("funnel", 27), ("ill-normal", 30), ("ar1", 33), ("normal", 41), ("ill-normal", 103)])
+@pytest.mark.parametrize("stem,D", [("funnel", 3), ("normal", 2), ("funnel", 5), ("funnel", 27), ("ill-normal", 30), ("ar1", 33), ("normal", 41), ("ill-normal", 103)])
 def test_quad_mode_ragged_dimensions(oracle, monkeypatch, kernel_mode, stem, D, form):
     """Quad mode of the 16-chain tiles (four lanes per chain, coordinate i = 4 step + q; klhr_split.hpp) at dimensions that are NOT
-    multiples of four (a last, partial step; D = 5: one whole step), on every separable target, through two window closures (the
+    multiples of four (a last, partial step; D = 5: one whole step; D = 2, 3: no whole step), on every separable target, through two window closures (the
     rank rule, the column norms and the direction cache are written by four lanes per chain) and with the direction's normals
     drawn four per round from the generator's stride-4 recurrence (device_rng.hpp: rng_std_normal_quad).
     (a) Against lane = chain (64-chain tiles, the same pipeline without quad mode): every draw, the generator and the whole
