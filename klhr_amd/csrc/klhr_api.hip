@@ -357,11 +357,19 @@ extern "C" int klhr_create(const klhr_config *cfg, const double *model_data, siz
     const bool split_ok = (cfg->model_id == KLHR_MODEL_FUNNEL || cfg->model_id == KLHR_MODEL_ILL_NORMAL || cfg->model_id == KLHR_MODEL_NORMAL ||
                            (cfg->model_id == KLHR_MODEL_AR1 && !cfg->scale_dir_cov)) &&
                           cfg->variant != 3 && ((size_t)D * 16 + 512) * 8 <= 64 * 1024;
-    // default: the lane-per-chain kernel while a chain's row fits its LDS share (D <= 26), the split pipeline above that for
-    // the separable targets, the octet kernel for everything else.  KLHR_KERNEL = octet | lane | mono | split overrides
+    // default: the lane-per-chain kernel while a chain's row fits its LDS share (D <= 26) — from 16 385 chains on for the separable
+    // targets, see below —, the split pipeline above that dimension for the separable targets, the octet kernel for everything else.  KLHR_KERNEL = octet | lane | mono | split overrides
     // (mono: the monolithic kernel the dimension selects; split: the split pipeline wherever it is supported) — used by
     // the parity tests, which run every supported mapping.
-    s->split = split_ok && !s->use_lane;
+    // Dimension <= 26, separable target: lane kernel and split pipeline return the same bits (the lane kernel takes its line sums from the
+    // unnormalised direction as the streaming kernel does, and every form patches the clip bound per node: tools/lane_vs_split.py) — so the
+    // mapping may follow the chain count.  Up to 16 384 chains a lane-per-chain wavefront is 64 chains on one SIMD of 1 024 and an iteration
+    // lasts its 158 us whatever the count; the tile kernel spreads a chain over 4-8 lanes: funnel-10, us per iteration, lane kernel | tile
+    // kernel: 256-8 192 chains 158 | 78, 16 384: 158 | 129, 32 768: 169 | 277.  (Not with scale_dir_cov — the gradient's moments are formed
+    // differently in the two — and not ar1, which the lane kernel evaluates element-wise.)
+    const bool lane_equals_split = (cfg->model_id == KLHR_MODEL_FUNNEL || cfg->model_id == KLHR_MODEL_ILL_NORMAL || cfg->model_id == KLHR_MODEL_NORMAL) &&
+                                   !cfg->scale_dir_cov;
+    s->split = split_ok && (!s->use_lane || (lane_equals_split && s->C <= 16384));
     if (cfg->variant == 3) s->use_lane = false;          // the slice sampler runs on the octet kernel only
     else
     if (const char *kk = getenv("KLHR_KERNEL")) {

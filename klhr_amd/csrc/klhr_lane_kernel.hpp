@@ -31,7 +31,10 @@ __device__ __forceinline__ void lane_load_chunk(const T *src, int stride, int i0
 }
 
 // klhr_sinh.py:203-213 for the chain owned by this lane (sequential, unfused: rounds like NumPy)
-__device__ inline void lane_direction(const KParams &p, long long c, double2 *TR, const double *Z, double u_choice) {
+// Leaves r UNNORMALISED in TR[i].y and returns ||r + tol||: the caller takes the line sums from (theta, r) first — the split pipeline's
+// arithmetic (klhr_split.hpp: sums on r, scaled by 1 / ||r|| afterwards), so that both mappings hand the fit the same bits — and then
+// normalises (lane_normalise).
+__device__ inline double lane_direction(const KParams &p, long long c, double2 *TR, const double *Z, double u_choice) {
     const int D = p.D, nc = p.ncol;
     const double *ev = p.eigvals + c * nc;
     const double *evec = p.eigvecs + c * (long long)D * nc;
@@ -78,7 +81,9 @@ __device__ inline void lane_direction(const KParams &p, long long c, double2 *TR
             }
         }
     }
-    nn = sqrt(nn);
+    return sqrt(nn);
+}
+__device__ inline void lane_normalise(double2 *TR, int D, double nn) {
     for (int i = 0; i < D; i++) TR[i].y = TR[i].y / nn;
 }
 
@@ -404,6 +409,16 @@ __device__ __forceinline__ LineStat lane_line_stats(const KParams &p, const doub
 }
 
 #pragma clang fp contract(off)
+// the line sums of a freshly drawn direction, from (theta_i, r_i) with r still unnormalised and nn = ||r + tol||: the split pipeline's
+// operations in the split pipeline's order (sums on r, then B / nn, C / nn^2, max|r| / nn, r_0 / nn)
+template <int MODEL>
+__device__ __forceinline__ LineStat lane_line_stats_unnormalised(const KParams &p, const double2 *TR, double nn) {
+    LineStat st = lane_line_stats<MODEL>(p, TR);
+    const double inv = 1.0 / nn;
+    st.B = st.B * inv; st.C = st.C * inv * inv; st.m1 = st.m1 * inv;
+    if (MODEL == MODEL_FUNNEL) st.r0 = st.r0 / nn;
+    return st;
+}
 // contribution of ONE quadrature node to (KL, dKL/deta) from the line sums: per-node arithmetic identical whoever evaluates
 // it (the chain's own lane, or another lane in the node-shared tail), exact element-wise loop where the clip bound fails
 template <int MODEL, bool SUB>
@@ -417,7 +432,7 @@ __device__ __forceinline__ void cf_node(const KParams &p, const LineStat &st, co
     const double lch = log_cosh_from_exp(fabs(ac), fmin(E, Ei));
     const double t = fma(k.s_, sh, x0);
     double logp, gdot;
-    if (line_point<MODEL, true>(p, st, t, cl, logp, gdot)) {
+    if (line_point<MODEL, true>(p, st, t, cl, logp, gdot)) {      // the rare node behind the clip bound: the element-wise loop, for this node only
         const double t1[1] = {t};
         double lp1[1], gd1[1];
         model_eval_nv<MODEL, 1>(p.md, TR, t1, cl, lp1, gd1);
@@ -471,6 +486,7 @@ __device__ __forceinline__ void cf_eval_kl(const KParams &p, const LineStat &st,
                 any_need = any_need || need[n];
             }
             if (__any(any_need)) {
+                // (only the nodes whose own bound failed: the rule of every form of the KL evaluation, klhr_split.hpp included)
 #pragma unroll
                 for (int n = 0; n < 4; n++) {
                     if (need[n]) {
@@ -556,7 +572,13 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
             if (p.phases & PH_DIR) {
                 const double u_choice = (p.flags & FLAG_EIGEN_ONE) ? pcg_next_double(rng) : 0.0;
                 for (int k = 0; k < D; k++) Z[k] = rng_std_normal_call(rng);
-                lane_direction(p, c, TR, Z, u_choice);
+                const double nn_dir = lane_direction(p, c, TR, Z, u_choice);
+                if constexpr (is_separable<MODEL>()) {
+                    const LineStat sd = lane_line_stats_unnormalised<MODEL>(p, TR, nn_dir);
+                    double *sl = shx + LANE_ST + lane * 7;
+                    sl[0] = sd.v0; sl[1] = sd.r0; sl[2] = sd.A; sl[3] = sd.B; sl[4] = sd.C; sl[5] = sd.m0; sl[6] = sd.m1;
+                }
+                lane_normalise(TR, D, nn_dir);
                 if (p.flags & FLAG_DIAG) {
                     double *rg = p.d_rho + c * (long long)D;
                     for (int i = 0; i < D; i++) rg[i] = TR[i].y;
@@ -575,10 +597,15 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
             // two loops — the mode search runs opt_advance<N = 1> and never pays for a KL evaluation
             constexpr bool SUB = VARIANT == VAR_SUB, GAUSS = VARIANT == VAR_GAUSS;
             constexpr int NFIT = GAUSS ? 2 : (SUB ? 3 : 4);
-            const LineStat st = active ? lane_line_stats<MODEL>(p, TR) : LineStat{0, 0, 0, 0, 0, 0, 0};
+            // (a direction drawn in this launch left its line sums in the lane's slot; a given direction — klhr_fit — is normalised: nn = 1)
+            LineStat st = {0, 0, 0, 0, 0, 0, 0};
             {
                 double *sl = shx + LANE_ST + lane * 7;
-                sl[0] = st.v0; sl[1] = st.r0; sl[2] = st.A; sl[3] = st.B; sl[4] = st.C; sl[5] = st.m0; sl[6] = st.m1;
+                if (active && (p.phases & PH_DIR)) { st.v0 = sl[0]; st.r0 = sl[1]; st.A = sl[2]; st.B = sl[3]; st.C = sl[4]; st.m0 = sl[5]; st.m1 = sl[6]; }
+                else {
+                    if (active) st = lane_line_stats<MODEL>(p, TR);
+                    sl[0] = st.v0; sl[1] = st.r0; sl[2] = st.A; sl[3] = st.B; sl[4] = st.C; sl[5] = st.m0; sl[6] = st.m1;
+                }
             }
             Opt o;
             double fit_n2 = 0, fit_n3 = 0;
@@ -878,8 +905,13 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
             else zp = sa_T(rng_std_normal_call(rng), eta, p.tol, p.scale_clip, VARIANT == VAR_SUB);
             double lp2[2], gd2[2];
             if constexpr (is_separable<MODEL>()) {
-                // (the line sums of this iteration's direction: recomputed here rather than kept in registers across the fit)
-                const LineStat stm = lane_line_stats<MODEL>(p, TR);
+                // (the line sums of this iteration's direction: the fit's own, from the lane's LDS slot, when this launch drew the direction
+                //  and ran the fit; a stand-alone MH launch — klhr_metropolis — has a given, normalised direction)
+                LineStat stm;
+                if ((p.phases & PH_DIR) && (p.phases & PH_FIT)) {
+                    const double *sl = shx + LANE_ST + lane * 7;
+                    stm.v0 = sl[0]; stm.r0 = sl[1]; stm.A = sl[2]; stm.B = sl[3]; stm.C = sl[4]; stm.m0 = sl[5]; stm.m1 = sl[6];
+                } else stm = lane_line_stats<MODEL>(p, TR);
                 (void)line_point<MODEL, false>(p, stm, zp, INFINITY, lp2[0], gd2[0]);
                 (void)line_point<MODEL, false>(p, stm, 0.0, INFINITY, lp2[1], gd2[1]);
             } else {

@@ -114,7 +114,7 @@ __device__ __forceinline__ void split_kl_group(const KParams &p, const LineStat 
                                                const double *asx, const double *wq, double (&part)[5]) {
     double sh[4], ch[4], lch[4], t[4], av[4], logp[4], gdot[4];
     const double cl = SUB ? p.grad_clip : p.scale_clip;
-    bool need = false;
+    bool need = false, need_n[4];
 #pragma unroll
     for (int n = 0; n < 4; n++) {
         const double a = (asx[n] + k.esh) * k.invd;
@@ -125,14 +125,17 @@ __device__ __forceinline__ void split_kl_group(const KParams &p, const LineStat 
         lch[n] = log_cosh_from_exp(fabs(ac), fmin(E, Ei));
         t[n] = fma(k.s_, sh[n], x0);
         av[n] = a;
-        need = line_point<MODEL, true>(p, st, t[n], cl, logp[n], gdot[n]) || need;
+        need_n[n] = line_point<MODEL, true>(p, st, t[n], cl, logp[n], gdot[n]);
+        need = need || need_n[n];
     }
     if (__any(need)) {
+        // the rare node behind the clip bound takes the element-wise value — that node only, in every form of the KL evaluation (the lane
+        // kernel's cf_eval_kl / cf_node, node_eval_kl below), so that the forms and the mappings return the same bits
         if (need) {
             const long long tb = tile_base(c, p.D, p.tw);
             const Pts4 e = exact_points4<MODEL>(p.theta + tb, p.d_rho + tb, p.md.aux, p.D, p.tw, p.md.n, nn, t[0], t[1], t[2], t[3], cl);
 #pragma unroll
-            for (int n = 0; n < 4; n++) { logp[n] = e.lp[n]; gdot[n] = e.gd[n]; }
+            for (int n = 0; n < 4; n++) if (need_n[n]) { logp[n] = e.lp[n]; gdot[n] = e.gd[n]; }
         }
     }
     double cc[4][5];
@@ -225,9 +228,8 @@ __device__ __forceinline__ void node_eval_kl(const KParams &p, const LineStat &s
         double logp, gdot;
         bool need = line_point<MODEL, true>(p, st, t, cl, logp, gdot);
         if (__any(need)) {
-            // the rare point behind the clip bound: the element-wise loop — for all four nodes of its half, as split_kl_group
-            // does (exact_points4 takes four points; here each lane passes its own four times)
-            need = ((__ballot(need) >> (threadIdx.x & 60)) & 0xFull) != 0;
+            // the rare point behind the clip bound: the element-wise loop, for this node only (exact_points4 takes four points; the lane
+            // passes its own four times)
             if (need) {
                 const long long tb = tile_base(c, p.D, p.tw);
                 const Pts4 e = exact_points4<MODEL>(p.theta + tb, p.d_rho + tb, p.md.aux, p.D, p.tw, p.md.n, nn, t, t, t, t, cl);

@@ -81,11 +81,12 @@ def test_odd_chain_counts_every_variant(name):
                     assert np.array_equal(th[0], first), (name, variant, over, C)
 
 
-@pytest.mark.parametrize("name", ["funnel100", "ar1x100"])
+@pytest.mark.parametrize("name", ["funnel100", "ar1x100", "funnel10"])
 def test_mapping_thresholds_do_not_show_in_a_chain(name):
     """The split pipeline switches mappings with the chain count: whole iterations per 16-chain tile (quad mode: four lanes per
     chain) in one launch up to 16 384 chains — the one-wavefront-per-SIMD build up to 8 192, the two-per-SIMD build above —,
     64-chain tiles (lane = chain) above; the node-parallel fit kernel up to 32 768 chains, the lane = chain fit kernels above.
+    Dimension <= 26 (funnel10): the tile kernel up to 16 384 chains, the lane-per-chain kernel from 16 385 on.
     The first chains' states after 60 draws (first window closure included) are the same bits on both sides of each threshold
     and in a small launch."""
     stem, data = model_spec(name)

@@ -888,10 +888,10 @@ def test_exact_patch_draws_vs_oracle(oracle, monkeypatch, kernel_mode, name, for
 
 
 @pytest.mark.parametrize("form", ["tile", "fitn"])
-@pytest.mark.parametrize("stem,D", [("funnel", 3), ("normal", 2), ("funnel", 5), ("funnel", 27), ("ill-normal", 30), ("ar1", 33), ("normal", 41), ("ill-normal", 103)])
+@pytest.mark.parametrize("stem,D", [("funnel", 2), ("normal", 2), ("funnel", 4), ("funnel", 26), ("ill-normal", 30), ("ar1", 33), ("normal", 41), ("ill-normal", 103)])
 def test_quad_mode_ragged_dimensions(oracle, monkeypatch, kernel_mode, stem, D, form):
     """Quad mode of the 16-chain tiles (four lanes per chain, coordinate i = 4 step + q; klhr_split.hpp) at dimensions that are NOT
-    multiples of four (a last, partial step; D = 5: one whole step; D = 2, 3: no whole step), on every separable target, through two window closures (the
+    multiples of four (a last, partial step; no whole step at dimension 2 and 3; the funnel's dimension is its data's D + 1: 3, 5, 27), on every separable target, through two window closures (the
     rank rule, the column norms and the direction cache are written by four lanes per chain) and with the direction's normals
     drawn four per round from the generator's stride-4 recurrence (device_rng.hpp: rng_std_normal_quad).
     (a) Against lane = chain (64-chain tiles, the same pipeline without quad mode): every draw, the generator and the whole
@@ -937,7 +937,7 @@ def test_quad_mode_ragged_dimensions(oracle, monkeypatch, kernel_mode, stem, D, 
 @pytest.mark.parametrize("opts", [dict(variant=1), dict(variant=1, overrelaxed=True), dict(variant=2), dict(overrelaxed=True), dict(scale_dir_cov=True),
                                   dict(eigen_method_one=True), dict(J=3), dict(J=1)],
                          ids=["klhr", "klhr-overrelaxed", "sub", "overrelaxed", "scale_dir_cov", "eigen_method_one", "J3", "J1"])
-@pytest.mark.parametrize("stem,D", [("funnel", 27), ("ill-normal", 30)])
+@pytest.mark.parametrize("stem,D", [("funnel", 26), ("ill-normal", 30)])
 def test_quad_mode_variants_and_flags_equal_lane_per_chain(monkeypatch, kernel_mode, stem, D, opts):
     """Every sampler variant and flag of the split pipeline through quad mode (16-chain tiles: the tile kernel AND the kernel sequence
     in pair mode) at a dimension with a partial last step, against lane = chain (64-chain tiles): 70 draws through two closures, the
@@ -968,3 +968,42 @@ def test_quad_mode_variants_and_flags_equal_lane_per_chain(monkeypatch, kernel_m
         assert np.array_equal(dq, d64, equal_nan=True), (stem, D, opts, form, int(np.argmax((dq != d64).any(axis=(1, 2)))))
         for f in fields:
             assert np.array_equal(stq[f], st64[f], equal_nan=True), (stem, D, opts, form, f)
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(variant=1), dict(variant=1, overrelaxed=True), dict(variant=2), dict(overrelaxed=True), dict(eigen_method_one=True),
+                                  dict(scale_clip=3.0, grad_clip=3.0)],
+                         ids=["sinh", "klhr", "klhr-overrelaxed", "sub", "overrelaxed", "eigen_method_one", "clip3"])
+@pytest.mark.parametrize("stem,D", [("funnel", 9), ("funnel", 1), ("ill-normal", 26), ("normal", 3)])
+def test_lane_kernel_equals_split_pipeline(monkeypatch, kernel_mode, stem, D, opts):
+    """Dimension <= 26, separable targets: the lane-per-chain kernel and the split pipeline (tile kernel, kernel sequence on 16-chain and on
+    64-chain tiles with the lane = chain fit) return the SAME BITS — draws, generator, adaptation state, evaluation counts — over 160 draws
+    through both closures of warmup = 100.  This is what lets klhr_create choose the mapping by the chain count (tile kernel up to 16 384
+    chains, lane kernel above) without the choice showing in a chain.  Two things make it so: the lane kernel takes its line sums from the
+    unnormalised direction and scales them by 1 / ||r||, as the streaming kernel does, and every form of the KL evaluation replaces the
+    closed form by the element-wise value for exactly the nodes whose own clip bound fails (clip3: nearly every evaluation)."""
+    if kernel_mode != "auto":
+        pytest.skip("this test selects the mappings itself")
+    data = {"D": D}
+    kw = dict(warmup=100, **opts)
+    C, n = 72, 160
+    seeds = np.arange(C, dtype=np.uint64) + 7300 + D
+    fields = STATE_FIELDS + ["acc", "grad_evals", "counters", "status"]
+
+    def run(env):
+        for k in ("KLHR_KERNEL", "KLHR_FITN", "KLHR_FUSED", "KLHR_TILE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        s = make_sampler(stem, data, C, **kw)
+        s.seed(seeds)
+        s.step(n, record_draws=True)
+        return s.kernel_name(), s.draws(0, n), {f: s.get(f) for f in fields}
+
+    name0, d0, st0 = run({"KLHR_KERNEL": "lane"})
+    assert name0 == "klhr_lane_kernel", name0
+    for env in ({}, {"KLHR_KERNEL": "split", "KLHR_FUSED": "0"}, {"KLHR_KERNEL": "split", "KLHR_FUSED": "0", "KLHR_TILE": "64", "KLHR_FITN": "0"}):
+        name, d, st = run(env)
+        assert "lane" not in name, (name, env)          # (the default mapping at 72 chains is the tile kernel)
+        assert np.array_equal(d, d0, equal_nan=True), (stem, D, opts, name, int(np.argmax((d != d0).any(axis=(1, 2)))))
+        for f in fields:
+            assert np.array_equal(st[f], st0[f], equal_nan=True), (stem, D, opts, name, f)
