@@ -567,21 +567,19 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
 #endif
     for (int iter = 0; iter < p.n_iters; ++iter) {
         KLHR_STAMP(st_out);
+        double nn_dir = 1.0;
         // =============================================================== direction
         if (active) {
             if (p.phases & PH_DIR) {
                 const double u_choice = (p.flags & FLAG_EIGEN_ONE) ? pcg_next_double(rng) : 0.0;
                 for (int k = 0; k < D; k++) Z[k] = rng_std_normal_call(rng);
-                const double nn_dir = lane_direction(p, c, TR, Z, u_choice);
-                if constexpr (is_separable<MODEL>()) {
-                    const LineStat sd = lane_line_stats_unnormalised<MODEL>(p, TR, nn_dir);
-                    double *sl = shx + LANE_ST + lane * 7;
-                    sl[0] = sd.v0; sl[1] = sd.r0; sl[2] = sd.A; sl[3] = sd.B; sl[4] = sd.C; sl[5] = sd.m0; sl[6] = sd.m1;
-                }
-                lane_normalise(TR, D, nn_dir);
+                nn_dir = lane_direction(p, c, TR, Z, u_choice);
+                // (separable target with the fit in this launch: the fit's head takes the line sums from the unnormalised direction first)
+                if (!(is_separable<MODEL>() && (p.phases & PH_FIT))) lane_normalise(TR, D, nn_dir);
                 if (p.flags & FLAG_DIAG) {
                     double *rg = p.d_rho + c * (long long)D;
-                    for (int i = 0; i < D; i++) rg[i] = TR[i].y;
+                    const bool unn = is_separable<MODEL>() && (p.phases & PH_FIT);
+                    for (int i = 0; i < D; i++) rg[i] = unn ? TR[i].y / nn_dir : TR[i].y;
                 }
             } else {
                 const double *rg = p.d_rho + c * (long long)D;
@@ -597,15 +595,16 @@ __global__ __launch_bounds__(64, 1) void klhr_lane_kernel(const KParams p) {
             // two loops — the mode search runs opt_advance<N = 1> and never pays for a KL evaluation
             constexpr bool SUB = VARIANT == VAR_SUB, GAUSS = VARIANT == VAR_GAUSS;
             constexpr int NFIT = GAUSS ? 2 : (SUB ? 3 : 4);
-            // (a direction drawn in this launch left its line sums in the lane's slot; a given direction — klhr_fit — is normalised: nn = 1)
+            // (a direction drawn in this launch is still unnormalised: its line sums are the split pipeline's — sums on r, scaled by 1 / ||r|| —,
+            //  then it is normalised; a given direction — klhr_fit — is normalised already: nn = 1)
             LineStat st = {0, 0, 0, 0, 0, 0, 0};
+            if (active) {
+                if (p.phases & PH_DIR) { st = lane_line_stats_unnormalised<MODEL>(p, TR, nn_dir); lane_normalise(TR, D, nn_dir); }
+                else st = lane_line_stats<MODEL>(p, TR);
+            }
             {
                 double *sl = shx + LANE_ST + lane * 7;
-                if (active && (p.phases & PH_DIR)) { st.v0 = sl[0]; st.r0 = sl[1]; st.A = sl[2]; st.B = sl[3]; st.C = sl[4]; st.m0 = sl[5]; st.m1 = sl[6]; }
-                else {
-                    if (active) st = lane_line_stats<MODEL>(p, TR);
-                    sl[0] = st.v0; sl[1] = st.r0; sl[2] = st.A; sl[3] = st.B; sl[4] = st.C; sl[5] = st.m0; sl[6] = st.m1;
-                }
+                sl[0] = st.v0; sl[1] = st.r0; sl[2] = st.A; sl[3] = st.B; sl[4] = st.C; sl[5] = st.m0; sl[6] = st.m1;
             }
             Opt o;
             double fit_n2 = 0, fit_n3 = 0;
