@@ -96,12 +96,13 @@ KLHR_API int klhr_dim(const klhr_sampler *s);                  /* replaces BSMod
 KLHR_API int klhr_chains(const klhr_sampler *s);
 KLHR_API int klhr_sync(klhr_sampler *s);                       /* wait for the handle's stream */
 /* which hot-path kernels this handle launches: 0 = octet-per-chain (klhr_iter_kernel), 1 = lane-per-chain
- * (klhr_lane_kernel, model dimension <= 26), 2 = split-phase pipeline: streaming kernel + klhr_fit12_kernel (both fit
+ * (klhr_lane_kernel, model dimension <= 26; separable targets only from 16 385 chains on — below that they run as 5, with
+ * the same bits), 2 = split-phase pipeline: streaming kernel + klhr_fit12_kernel (both fit
  * stages lane = chain; funnel / ill-normal / normal / ar1 above dimension 26), 3 = split-phase pipeline with both fit
  * stages in the node-parallel klhr_fitn_kernel (up to 32 768 chains), 5 = as 3, and klhr_step runs whole iterations per
  * 16-chain tile in one launch (klhr_tile_kernel: up to 16 384 chains, ill-normal / normal / ar1 up to 32 768; the pieces
  * of the C ABI and diagnostic steps use the kernels of 3).  (4 was the hand-over mode removed in round 3.)  Results agree within the stated tolerances
- * (2, 3, 5: bit for bit); only the mapping to the machine differs.  KLHR_KERNEL = octet | lane | mono | split in the
+ * (2, 3, 5 and, for funnel / ill-normal / normal without scale_dir_cov, 1: bit for bit); only the mapping to the machine differs.  KLHR_KERNEL = octet | lane | mono | split in the
  * environment overrides.
  * klhr_tile_width: chains per tile of the split pipeline's state layout — 64 (klhr_stream_kernel) or 16
  * (klhr_stream16_kernel / klhr_tile_kernel, four lanes per chain; the range of variant 5); 0 for the monolithic kernels. */
